@@ -1,0 +1,102 @@
+"""ctypes binding of ``libdm_hip.so`` (the C ABI declared in ``include/dm_hip.h``).
+
+The library is built in-tree by ``build.py`` (``hipcc --offload-arch=gfx950``).  There is no
+fallback: if it is missing or a call fails, a ``RuntimeError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdm_hip.so")
+
+DM_F32, DM_BF16 = 0, 1
+EPI_PLAIN, EPI_GEGLU, EPI_NCHW_F32 = 0, 1, 2
+TILE_AUTO, TILE_128x128, TILE_64x128, TILE_64x64, TILE_256x128, TILE_32x64 = 0, 1, 2, 3, 4, 5
+TILE_DIMS = {TILE_128x128: (128, 128), TILE_64x128: (64, 128), TILE_64x64: (64, 64),
+             TILE_256x128: (256, 128), TILE_32x64: (32, 64)}
+
+_ERR = {1: "invalid argument / unsupported shape", 2: "HIP launch error", 3: "misaligned pointer or stride"}
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p), ("lda", C.c_long),
+        ("w", C.c_void_p),
+        ("c", C.c_void_p), ("ldc", C.c_long),
+        ("bias", C.c_void_p),
+        ("rowbias", C.c_void_p), ("ld_rowbias", C.c_long), ("rows_per_batch", C.c_int),
+        ("r", C.c_void_p), ("ldr", C.c_long),
+        ("m", C.c_int), ("n", C.c_int), ("k", C.c_int),
+        ("npad", C.c_int), ("kpad", C.c_int),
+        ("dtype", C.c_int),
+        ("conv", C.c_int),
+        ("hin", C.c_int), ("win", C.c_int), ("hout", C.c_int), ("wout", C.c_int),
+        ("cin", C.c_int), ("stride", C.c_int), ("up", C.c_int),
+        ("epi", C.c_int),
+        ("tile", C.c_int),
+        ("splitk", C.c_int),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_long),
+    ]
+
+
+_vp, _l, _i, _f = C.c_void_p, C.c_long, C.c_int, C.c_float
+_PROTOS = {
+    "dm_abi_version": (C.c_int, []),
+    "dm_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "dm_gemm_plan": (None, [_i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "dm_gemm_workspace_bytes": (C.c_long, [_i, _i, _i]),
+    "dm_pack_weight_order": (C.c_int, [_i, _i, _i, _vp]),
+    "dm_groupnorm_stats": (C.c_int, [_vp, _l, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "dm_groupnorm_apply": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp]),
+    "dm_layernorm": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _f, _vp]),
+    "dm_attention": (C.c_int, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _vp]),
+    "dm_transpose_v": (C.c_int, [_vp, _l, _i, _i, _i, _i, _vp, _l, _i, _vp]),
+    "dm_linear_rows": (C.c_int, [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
+    "dm_timestep_embedding": (C.c_int, [_vp, _i, _i, _f, _vp, _vp]),
+    "dm_ddpm_step": (C.c_int, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp]),
+    "dm_ddim_step": (C.c_int, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp]),
+    "dm_scale_add": (C.c_int, [_vp, _vp, _vp, _i, _l, _vp, _vp, _vp, _f, _vp]),
+    "dm_axpbypcz": (C.c_int, [_vp, _f, _vp, _f, _vp, _f, _vp, _l, _vp]),
+    "dm_nchw_to_rows": (C.c_int, [_vp, _i, _i, _i, _vp, _l, _i, _i, _vp]),
+    "dm_rows_to_nchw": (C.c_int, [_vp, _l, _i, _i, _i, _vp, _i, _vp]),
+    "dm_convert": (C.c_int, [_vp, _i, _vp, _i, _l, _vp]),
+    "dm_gather_row": (C.c_int, [_vp, _l, _vp, _vp, _l, _i, _i, _vp]),
+    "dm_advance_counter": (C.c_int, [_vp, _i, _vp]),
+    "dm_graph_begin": (C.c_int, [_vp]),
+    "dm_graph_end": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "dm_graph_launch": (C.c_int, [_vp, _vp]),
+    "dm_graph_destroy": (C.c_int, [_vp]),
+    "dm_event_create": (C.c_int, [C.POINTER(_vp)]),
+    "dm_event_record": (C.c_int, [_vp, _vp]),
+    "dm_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(_f)]),
+    "dm_event_destroy": (C.c_int, [_vp]),
+}
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the HIP extension; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"HIP extension not built: {LIB_PATH} is missing. Run `python build.py` (needs hipcc); "
+                "diffusion_model_amd has no CPU or PyTorch fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.dm_abi_version() != 1:
+            raise RuntimeError("libdm_hip.so ABI version mismatch; rebuild with `python build.py`")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise RuntimeError(f"libdm_hip {what} failed: {_ERR.get(rc, rc)}")

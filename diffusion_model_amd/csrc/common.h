@@ -1,0 +1,116 @@
+// Shared device helpers for the gfx950 (MI355X, CDNA4) kernels of the denoising hot path.
+//
+// Conventions used by every kernel in this directory:
+//   * wavefront = 64 lanes; block = 256 threads (4 waves) unless stated otherwise
+//   * activations are row-major [rows][ld] with the channel dimension contiguous
+//     ("NHWC": row = (batch, y, x)); every tensor argument carries its own leading dimension
+//   * two storage types: float (fp32 mode, exact f32 MFMA) and bf16 (bf16 mode, f32 accumulate)
+//   * a "chunk" is 16 bytes of the contraction dimension: 4 floats or 8 bf16
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+typedef uint16_t bf16_t;  // storage type of a bf16 element
+
+#define DM_WAVE 64
+
+// ---- error codes returned through the C ABI -------------------------------------------------
+#define DM_OK 0
+#define DM_ERR_ARG 1      // invalid argument / unsupported shape
+#define DM_ERR_LAUNCH 2   // HIP reported a launch error
+#define DM_ERR_ALIGN 3    // pointer or leading dimension not 16-byte aligned
+
+// ---- scalar conversions -----------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
+    return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+    static constexpr int EPC = 4;  // elements per 16-byte chunk
+    __device__ static __forceinline__ float load(const float* p) { return *p; }
+    __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct ElemTraits<bf16_t> {
+    static constexpr int EPC = 8;
+    __device__ static __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+    __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// Expand one 16-byte chunk to floats / pack floats back into a chunk.
+template <typename T> __device__ __forceinline__ void chunk_to_f32(const u32x4& c, float* out);
+template <> __device__ __forceinline__ void chunk_to_f32<float>(const u32x4& c, float* out) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = __uint_as_float(c[i]);
+}
+template <> __device__ __forceinline__ void chunk_to_f32<bf16_t>(const u32x4& c, float* out) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        out[2 * i] = __uint_as_float(c[i] << 16);
+        out[2 * i + 1] = __uint_as_float(c[i] & 0xffff0000u);
+    }
+}
+template <typename T> __device__ __forceinline__ u32x4 f32_to_chunk(const float* in);
+template <> __device__ __forceinline__ u32x4 f32_to_chunk<float>(const float* in) {
+    u32x4 c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = __float_as_uint(in[i]);
+    return c;
+}
+template <> __device__ __forceinline__ u32x4 f32_to_chunk<bf16_t>(const float* in) {
+    u32x4 c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = pack_bf16x2(in[2 * i], in[2 * i + 1]);
+    return c;
+}
+
+// ---- 16x16 MFMA over one chunk per lane -----------------------------------------------------
+// D[i][j] += sum_k A[i][k] * B[k][j] for a 16x16 output tile.  Lane l supplies, as 16 bytes,
+// A[i = l&15][chunk l>>4] and B[chunk l>>4][j = l&15]; the four lane groups together cover a
+// "k-step" of 64 bytes of the contraction dimension (32 bf16 or 16 floats).
+// Result layout: lane l holds D[i = 4*(l>>4) + r][j = l&15] in element r.
+//   bf16 : one v_mfma_f32_16x16x32_bf16
+//   float: four v_mfma_f32_16x16x4_f32, the e-th using element e of each lane's chunk (a
+//          permutation of k that is identical on both operands, so the sum is unchanged)
+template <typename T> struct Mma16;
+template <> struct Mma16<bf16_t> {
+    __device__ static __forceinline__ void mma(f32x4& acc, const u32x4& a, const u32x4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                      acc, 0, 0, 0);
+    }
+};
+template <> struct Mma16<float> {
+    __device__ static __forceinline__ void mma(f32x4& acc, const u32x4& a, const u32x4& b) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b[e]), acc, 0, 0, 0);
+    }
+};
+
+// ---- activations ----------------------------------------------------------------------------------
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// 16-byte global load with a zero default (predicated-off lanes read nothing).
+__device__ __forceinline__ u32x4 ldg16(const void* p, bool pred) {
+    u32x4 z = {0u, 0u, 0u, 0u};
+    return pred ? *reinterpret_cast<const u32x4*>(p) : z;
+}
+
+static inline int dm_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DM_OK : DM_ERR_LAUNCH;
+}
+static inline bool dm_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -1,0 +1,364 @@
+// Bandwidth-bound pieces of the sampling loop: the fused reverse-process update, the small fp32
+// Linears of the time path, layout/dtype conversion at the model boundary, and the hipGraph /
+// event plumbing exported through the C ABI.
+#include "common.h"
+#include "dm_hip.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+inline int ew_blocks(long n_items) {
+    long b = (n_items + EW_THREADS - 1) / EW_THREADS;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---- reverse-process update ------------------------------------------------------------------------
+// Each arithmetic step is a separately rounded fp32 operation (no FMA contraction), in the order
+// the reference's tensor expression evaluates them, so the result is bitwise what fp32 torch gives.
+template <bool SECOND_IS_EPS>
+__global__ __launch_bounds__(EW_THREADS) void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                                const float* __restrict__ noise, float* __restrict__ out,
+                                                                long n, const float* __restrict__ coef,
+                                                                const int* __restrict__ step_index, int clip) {
+    long shift = 0;
+    if (step_index) {
+        const int s = *step_index;
+        coef += 5 * s;
+        shift = (long)s * n;
+    }
+    const float c_eps = coef[0], c_div = coef[1], c_x0 = coef[2], c_xt = coef[3], c_nz = coef[4];
+    const bool add_noise = noise != nullptr && c_nz != 0.0f;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 ev = reinterpret_cast<const f32x4*>(eps)[i];
+        f32x4 nv = {0.f, 0.f, 0.f, 0.f};
+        if (add_noise) nv = reinterpret_cast<const f32x4*>(noise + shift)[i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x0 = __fdiv_rn(__fsub_rn(xv[e], __fmul_rn(c_eps, ev[e])), c_div);
+            if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+            float prev = __fadd_rn(__fmul_rn(c_x0, x0), __fmul_rn(c_xt, SECOND_IS_EPS ? ev[e] : xv[e]));
+            if (add_noise) prev = __fadd_rn(prev, __fmul_rn(c_nz, nv[e]));
+            o[e] = prev;
+        }
+        reinterpret_cast<f32x4*>(out)[i] = o;
+    }
+    // tail (n not a multiple of 4)
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float x0 = __fdiv_rn(__fsub_rn(x[i], __fmul_rn(c_eps, eps[i])), c_div);
+        if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        float prev = __fadd_rn(__fmul_rn(c_x0, x0), __fmul_rn(c_xt, SECOND_IS_EPS ? eps[i] : x[i]));
+        if (add_noise) prev = __fadd_rn(prev, __fmul_rn(c_nz, noise[shift + i]));
+        out[i] = prev;
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void scale_add_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                float* __restrict__ out, long per_sample,
+                                                                const float* __restrict__ ta, const float* __restrict__ tc,
+                                                                const long long* __restrict__ t, float sign_c) {
+    const int b = blockIdx.y;
+    const float a = ta[t[b]], c = sign_c * tc[t[b]];
+    const long base = (long)b * per_sample;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += (long)gridDim.x * blockDim.x)
+        out[base + i] = __fadd_rn(__fmul_rn(a, x[base + i]), __fmul_rn(c, y[base + i]));
+}
+
+__global__ __launch_bounds__(EW_THREADS) void axpbypcz_kernel(const float* __restrict__ x, float alpha,
+                                                               const float* __restrict__ y, float beta,
+                                                               const float* __restrict__ z, float gamma,
+                                                               float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = __fmul_rn(alpha, x[i]);
+        if (y) v = __fadd_rn(v, __fmul_rn(beta, y[i]));
+        if (z) v = __fadd_rn(v, __fmul_rn(gamma, z[i]));
+        out[i] = v;
+    }
+}
+
+// ---- time path: y[b][n] = sum_k f(x[b][k]) w[n][k] + bias[n]; one wave per output column ----------
+constexpr int LR_BATCH = 8;
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y, long ldy,
+                                                          int batch, int n, int k, int silu_in) {
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= n) return;
+    const float* wr = w + (long)col * k;
+    for (int b0 = 0; b0 < batch; b0 += LR_BATCH) {
+        float acc[LR_BATCH];
+#pragma unroll
+        for (int i = 0; i < LR_BATCH; ++i) acc[i] = 0.f;
+        for (int kk = lane * 4; kk < k; kk += 256) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + kk);
+#pragma unroll
+            for (int i = 0; i < LR_BATCH; ++i) {
+                if (b0 + i < batch) {
+                    f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long)(b0 + i) * ldx + kk);
+                    if (silu_in) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xv[e] = silu_f(xv[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i] = fmaf(xv[e], wv[e], acc[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LR_BATCH; ++i) {
+            float v = acc[i];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0 && b0 + i < batch) y[(long)(b0 + i) * ldy + col] = v + (bias ? bias[col] : 0.f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void timestep_embedding_kernel(const long long* __restrict__ t, int batch, int dim,
+                                                                        float log_max_period, float* __restrict__ out) {
+    const int half = dim >> 1;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < batch * dim; idx += gridDim.x * blockDim.x) {
+        const int b = idx / dim, j = idx - b * dim;
+        float v = 0.f;
+        if (j < 2 * half) {
+            const int i = j < half ? j : j - half;
+            const float freq = expf(__fdiv_rn(__fmul_rn(-log_max_period, (float)i), (float)half));
+            const float arg = __fmul_rn((float)t[b], freq);
+            v = j < half ? cosf(arg) : sinf(arg);
+        }
+        out[idx] = v;
+    }
+}
+
+// ---- layout conversion: fp32 NCHW  <->  [rows = (b, pixel)][channels] in the engine's dtype ----------
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_rows_kernel(const float* __restrict__ src, int c, int hw, T* __restrict__ dst,
+                                                           long ld, int cpad) {
+    __shared__ float tile[64][65];
+    const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {  // i: channel within tile, tx: pixel
+        const int ch = c0 + i, p = p0 + tx;
+        tile[i][tx] = (ch < c && p < hw) ? src[((long)b * c + ch) * hw + p] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {  // i: pixel within tile, tx: channel
+        const int ch = c0 + tx, p = p0 + i;
+        if (ch < cpad && p < hw) ElemTraits<T>::store(dst + ((long)b * hw + p) * ld + ch, tile[tx][i]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rows_to_nchw_kernel(const T* __restrict__ src, long ld, int c, int hw,
+                                                           float* __restrict__ dst) {
+    __shared__ float tile[64][65];
+    const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {  // i: pixel, tx: channel
+        const int ch = c0 + tx, p = p0 + i;
+        tile[i][tx] = (ch < c && p < hw) ? ElemTraits<T>::load(src + ((long)b * hw + p) * ld + ch) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {  // i: channel, tx: pixel
+        const int ch = c0 + i, p = p0 + tx;
+        if (ch < c && p < hw) dst[((long)b * c + ch) * hw + p] = tile[tx][i];
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void f32_to_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        d[i] = f32_to_bf16(s[i]);
+}
+__global__ __launch_bounds__(EW_THREADS) void bf16_to_f32_kernel(const bf16_t* __restrict__ s, float* __restrict__ d, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        d[i] = bf16_to_f32(s[i]);
+}
+
+__global__ __launch_bounds__(EW_THREADS) void gather_row_kernel(const float* __restrict__ table, long ld,
+                                                                 const int* __restrict__ index, float* __restrict__ dst,
+                                                                 long ld_dst, int batch, int n) {
+    const float* row = table + (long)(*index) * ld;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < batch * n; idx += gridDim.x * blockDim.x) {
+        const int b = idx / n, j = idx - b * n;
+        dst[(long)b * ld_dst + j] = row[j];
+    }
+}
+
+// Single-lane vector load/store; every other launch on the stream is ordered after it.
+__global__ void advance_counter_kernel(int* counter, int delta) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int v = *reinterpret_cast<volatile int*>(counter);
+        *reinterpret_cast<volatile int*>(counter) = v + delta;
+    }
+}
+
+}  // namespace
+
+extern "C" int dm_abi_version(void) { return DM_ABI_VERSION; }
+
+static int reverse_step_launch(bool second_is_eps, const float* x, const float* eps, const float* noise, float* out,
+                               long n, const float* coef, const int* step_index, int clip, hipStream_t stream) {
+    if (!x || !eps || !out || !coef || n <= 0) return DM_ERR_ARG;
+    if (!dm_aligned16(x) || !dm_aligned16(eps) || !dm_aligned16(out) || (noise && !dm_aligned16(noise)) ||
+        (step_index && noise && (n & 3)))
+        return DM_ERR_ALIGN;
+    const dim3 grid(ew_blocks((n + 3) / 4)), block(EW_THREADS);
+    if (second_is_eps)
+        hipLaunchKernelGGL(ddpm_step_kernel<true>, grid, block, 0, stream, x, eps, noise, out, n, coef, step_index, clip);
+    else
+        hipLaunchKernelGGL(ddpm_step_kernel<false>, grid, block, 0, stream, x, eps, noise, out, n, coef, step_index, clip);
+    return dm_check_launch();
+}
+
+extern "C" int dm_ddpm_step(const float* x, const float* eps, const float* noise, float* out, long n, const float* coef,
+                            const int* step_index, int clip, hipStream_t stream) {
+    return reverse_step_launch(false, x, eps, noise, out, n, coef, step_index, clip, stream);
+}
+
+extern "C" int dm_ddim_step(const float* x, const float* eps, const float* noise, float* out, long n, const float* coef,
+                            const int* step_index, int clip, hipStream_t stream) {
+    return reverse_step_launch(true, x, eps, noise, out, n, coef, step_index, clip, stream);
+}
+
+extern "C" int dm_scale_add(const float* x, const float* y, float* out, int batch, long per_sample, const float* ta,
+                            const float* tc, const long long* t, float sign_c, hipStream_t stream) {
+    if (!x || !y || !out || !ta || !tc || !t || batch <= 0 || per_sample <= 0) return DM_ERR_ARG;
+    hipLaunchKernelGGL(scale_add_kernel, dim3(ew_blocks(per_sample), batch), dim3(EW_THREADS), 0, stream, x, y, out,
+                       per_sample, ta, tc, t, sign_c);
+    return dm_check_launch();
+}
+
+extern "C" int dm_axpbypcz(const float* x, float alpha, const float* y, float beta, const float* z, float gamma,
+                           float* out, long n, hipStream_t stream) {
+    if (!x || !out || n <= 0) return DM_ERR_ARG;
+    hipLaunchKernelGGL(axpbypcz_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, stream, x, alpha, y, beta, z, gamma, out,
+                       n);
+    return dm_check_launch();
+}
+
+extern "C" int dm_linear_rows(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int batch,
+                              int n, int k, int silu_in, hipStream_t stream) {
+    if (!x || !w || !y || batch <= 0 || n <= 0 || k <= 0 || (k & 3) || (ldx & 3)) return DM_ERR_ARG;
+    if (!dm_aligned16(x) || !dm_aligned16(w)) return DM_ERR_ALIGN;
+    hipLaunchKernelGGL(linear_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, ldx, w, bias, y, ldy, batch, n, k,
+                       silu_in);
+    return dm_check_launch();
+}
+
+extern "C" int dm_timestep_embedding(const long long* timesteps, int batch, int dim, float max_period, float* out,
+                                     hipStream_t stream) {
+    if (!timesteps || !out || batch <= 0 || dim <= 0 || max_period <= 0.f) return DM_ERR_ARG;
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(ew_blocks((long)batch * dim)), dim3(EW_THREADS), 0, stream,
+                       timesteps, batch, dim, logf(max_period), out);
+    return dm_check_launch();
+}
+
+extern "C" int dm_nchw_to_rows(const float* src, int batch, int c, int hw, void* dst, long ld, int cpad, int dtype,
+                               hipStream_t stream) {
+    if (!src || !dst || batch <= 0 || c <= 0 || hw <= 0 || cpad < c || ld < cpad) return DM_ERR_ARG;
+    dim3 grid((hw + 63) / 64, (cpad + 63) / 64, batch);
+    if (dtype == DM_F32)
+        hipLaunchKernelGGL(nchw_to_rows_kernel<float>, grid, dim3(256), 0, stream, src, c, hw, static_cast<float*>(dst), ld,
+                           cpad);
+    else if (dtype == DM_BF16)
+        hipLaunchKernelGGL(nchw_to_rows_kernel<bf16_t>, grid, dim3(256), 0, stream, src, c, hw, static_cast<bf16_t*>(dst),
+                           ld, cpad);
+    else
+        return DM_ERR_ARG;
+    return dm_check_launch();
+}
+
+extern "C" int dm_rows_to_nchw(const void* src, long ld, int batch, int c, int hw, float* dst, int dtype,
+                               hipStream_t stream) {
+    if (!src || !dst || batch <= 0 || c <= 0 || hw <= 0 || ld < c) return DM_ERR_ARG;
+    dim3 grid((hw + 63) / 64, (c + 63) / 64, batch);
+    if (dtype == DM_F32)
+        hipLaunchKernelGGL(rows_to_nchw_kernel<float>, grid, dim3(256), 0, stream, static_cast<const float*>(src), ld, c, hw,
+                           dst);
+    else if (dtype == DM_BF16)
+        hipLaunchKernelGGL(rows_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, stream, static_cast<const bf16_t*>(src), ld, c,
+                           hw, dst);
+    else
+        return DM_ERR_ARG;
+    return dm_check_launch();
+}
+
+extern "C" int dm_convert(const void* src, int src_dtype, void* dst, int dst_dtype, long n, hipStream_t stream) {
+    if (!src || !dst || n <= 0) return DM_ERR_ARG;
+    if (src_dtype == DM_F32 && dst_dtype == DM_BF16)
+        hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, stream,
+                           static_cast<const float*>(src), static_cast<bf16_t*>(dst), n);
+    else if (src_dtype == DM_BF16 && dst_dtype == DM_F32)
+        hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, stream,
+                           static_cast<const bf16_t*>(src), static_cast<float*>(dst), n);
+    else
+        return DM_ERR_ARG;
+    return dm_check_launch();
+}
+
+extern "C" int dm_gather_row(const float* table, long ld, const int* index, float* dst, long ld_dst, int batch, int n,
+                             hipStream_t stream) {
+    if (!table || !index || !dst || batch <= 0 || n <= 0) return DM_ERR_ARG;
+    hipLaunchKernelGGL(gather_row_kernel, dim3(ew_blocks((long)batch * n)), dim3(EW_THREADS), 0, stream, table, ld, index,
+                       dst, ld_dst, batch, n);
+    return dm_check_launch();
+}
+
+extern "C" int dm_advance_counter(int* counter, int delta, hipStream_t stream) {
+    if (!counter) return DM_ERR_ARG;
+    hipLaunchKernelGGL(advance_counter_kernel, dim3(1), dim3(64), 0, stream, counter, delta);
+    return dm_check_launch();
+}
+
+// ---- hipGraph capture / replay -----------------------------------------------------------------------
+extern "C" int dm_graph_begin(hipStream_t stream) {
+    return hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess ? DM_OK : DM_ERR_LAUNCH;
+}
+
+extern "C" int dm_graph_end(hipStream_t stream, void** graph_exec_out) {
+    if (!graph_exec_out) return DM_ERR_ARG;
+    hipGraph_t graph = nullptr;
+    if (hipStreamEndCapture(stream, &graph) != hipSuccess || !graph) return DM_ERR_LAUNCH;
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) return DM_ERR_LAUNCH;
+    *graph_exec_out = exec;
+    return DM_OK;
+}
+
+extern "C" int dm_graph_launch(void* graph_exec, hipStream_t stream) {
+    if (!graph_exec) return DM_ERR_ARG;
+    return hipGraphLaunch(static_cast<hipGraphExec_t>(graph_exec), stream) == hipSuccess ? DM_OK : DM_ERR_LAUNCH;
+}
+
+extern "C" int dm_graph_destroy(void* graph_exec) {
+    if (!graph_exec) return DM_ERR_ARG;
+    return hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec)) == hipSuccess ? DM_OK : DM_ERR_LAUNCH;
+}
+
+// ---- events ------------------------------------------------------------------------------------------
+extern "C" int dm_event_create(void** ev) {
+    if (!ev) return DM_ERR_ARG;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return DM_ERR_LAUNCH;
+    *ev = e;
+    return DM_OK;
+}
+extern "C" int dm_event_record(void* ev, hipStream_t stream) {
+    return hipEventRecord(static_cast<hipEvent_t>(ev), stream) == hipSuccess ? DM_OK : DM_ERR_LAUNCH;
+}
+extern "C" int dm_event_elapsed_ms(void* start, void* stop, float* ms) {
+    if (!ms) return DM_ERR_ARG;
+    if (hipEventSynchronize(static_cast<hipEvent_t>(stop)) != hipSuccess) return DM_ERR_LAUNCH;
+    return hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)) == hipSuccess
+               ? DM_OK
+               : DM_ERR_LAUNCH;
+}
+extern "C" int dm_event_destroy(void* ev) {
+    return hipEventDestroy(static_cast<hipEvent_t>(ev)) == hipSuccess ? DM_OK : DM_ERR_LAUNCH;
+}

@@ -1,0 +1,311 @@
+// GroupNorm(+SiLU) and LayerNorm over channel-contiguous rows; HBM-bound, 16-byte accesses.
+//
+// GroupNorm statistics span (H*W) x (C/groups) elements per (sample, group), i.e. a strided
+// slice of every row.  Pass 1 cuts each sample's rows into `nsplit` slabs; a block sweeps its
+// slab with fully coalesced row reads, every thread owning fixed channel chunks so it can keep
+// per-channel (sum, sumsq) in registers, and reduces them to per-group partials in a fixed
+// order (bitwise reproducible).  Pass 2 folds the slab partials, then normalises + affine
+// (+ SiLU) with the same coalesced sweep.  The second read of x is served by the 256 MiB
+// Infinity Cache for every tensor on this path.
+#include "common.h"
+#include "dm_hip.h"
+
+namespace {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAX_SLOTS = 3;   // chunks per thread per row
+constexpr int GN_MAX_C = 5120;    // 3 fp32 LDS tables of C entries in pass 2 stay under 64 KB
+
+struct GnGeom {
+    int nchunks, slots, tpr, rpi;  // chunks per row, chunk slots per thread, threads per row, rows per iteration
+};
+
+template <typename T> __host__ __device__ inline GnGeom gn_geom(int c) {
+    GnGeom g;
+    g.nchunks = c / ElemTraits<T>::EPC;
+    g.slots = (g.nchunks + GN_THREADS - 1) / GN_THREADS;
+    g.tpr = (g.nchunks + g.slots - 1) / g.slots;
+    g.rpi = GN_THREADS / g.tpr;
+    return g;
+}
+
+template <typename T>
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restrict__ x, long ldx, int hw, int c,
+                                                               int groups, float* __restrict__ partial, int nsplit) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    __shared__ float red[GN_THREADS * GN_MAX_SLOTS * EPC * 2];
+    const GnGeom g = gn_geom<T>(c);
+    const int split = blockIdx.x, b = blockIdx.y;
+    const int rows_per = (hw + nsplit - 1) / nsplit;
+    const int r0 = split * rows_per, r1 = min(hw, r0 + rows_per);
+    const int tid = threadIdx.x;
+    const int lir = tid % g.tpr, rl = tid / g.tpr;
+    const bool active = rl < g.rpi;
+
+    float s[GN_MAX_SLOTS][EPC], q[GN_MAX_SLOTS][EPC];
+#pragma unroll
+    for (int k = 0; k < GN_MAX_SLOTS; ++k)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s[k][e] = q[k][e] = 0.f;
+
+    if (active) {
+        const T* base = x + ((long)b * hw) * ldx;
+        for (int row = r0 + rl; row < r1; row += g.rpi) {
+            const T* rp = base + (long)row * ldx;
+#pragma unroll
+            for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+                const int chunk = lir + k * g.tpr;
+                if (k < g.slots && chunk < g.nchunks) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(rp + chunk * EPC);
+                    float f[EPC];
+                    chunk_to_f32<T>(v, f);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        s[k][e] += f[e];
+                        q[k][e] = fmaf(f[e], f[e], q[k][e]);
+                    }
+                }
+            }
+        }
+    }
+    // red[rl][channel][2]
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+            const int chunk = lir + k * g.tpr;
+            if (k < g.slots && chunk < g.nchunks) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const int ch = chunk * EPC + e;
+                    red[(rl * c + ch) * 2] = s[k][e];
+                    red[(rl * c + ch) * 2 + 1] = q[k][e];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int ch = tid; ch < c; ch += GN_THREADS) {
+        float a = red[ch * 2], d = red[ch * 2 + 1];
+        for (int r = 1; r < g.rpi; ++r) {
+            a += red[(r * c + ch) * 2];
+            d += red[(r * c + ch) * 2 + 1];
+        }
+        red[ch * 2] = a;
+        red[ch * 2 + 1] = d;
+    }
+    __syncthreads();
+    const int cpg = c / groups;
+    for (int grp = tid; grp < groups; grp += GN_THREADS) {
+        float a = 0.f, d = 0.f;
+        for (int ch = grp * cpg; ch < (grp + 1) * cpg; ++ch) {
+            a += red[ch * 2];
+            d += red[ch * 2 + 1];
+        }
+        float* dst = partial + (((long)b * nsplit + split) * groups + grp) * 2;
+        dst[0] = a;
+        dst[1] = d;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y,
+                                                               long ldy, int hw, int c, int groups,
+                                                               const float* __restrict__ partial, int nsplit,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, int silu,
+                                                               int rows_per_block) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    extern __shared__ __attribute__((aligned(16))) float tab[];  // mean[c] | scale[c] | beta[c]
+    float* t_mean = tab;
+    float* t_scale = tab + c;
+    float* t_beta = tab + 2 * c;
+    __shared__ float g_mean[64], g_rstd[64];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int cpg = c / groups;
+    for (int grp = tid; grp < groups; grp += GN_THREADS) {
+        double a = 0.0, d = 0.0;
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const float* src = partial + (((long)b * nsplit + sp) * groups + grp) * 2;
+            a += (double)src[0];
+            d += (double)src[1];
+        }
+        const double n = (double)hw * cpg;
+        const double mean = a / n;
+        double var = d / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        g_mean[grp] = (float)mean;
+        g_rstd[grp] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int ch = tid; ch < c; ch += GN_THREADS) {
+        const int grp = ch / cpg;
+        t_mean[ch] = g_mean[grp];
+        t_scale[ch] = g_rstd[grp] * gamma[ch];
+        t_beta[ch] = beta[ch];
+    }
+    __syncthreads();
+
+    const GnGeom g = gn_geom<T>(c);
+    const int lir = tid % g.tpr, rl = tid / g.tpr;
+    if (rl >= g.rpi) return;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(hw, r0 + rows_per_block);
+    const T* xb = x + ((long)b * hw) * ldx;
+    T* yb = y + ((long)b * hw) * ldy;
+    for (int row = r0 + rl; row < r1; row += g.rpi) {
+#pragma unroll
+        for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+            const int chunk = lir + k * g.tpr;
+            if (k < g.slots && chunk < g.nchunks) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(xb + (long)row * ldx + chunk * EPC);
+                float f[EPC];
+                chunk_to_f32<T>(v, f);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const int ch = chunk * EPC + e;
+                    float o = (f[e] - t_mean[ch]) * t_scale[ch] + t_beta[ch];
+                    f[e] = silu ? silu_f(o) : o;
+                }
+                *reinterpret_cast<u32x4*>(yb + (long)row * ldy + chunk * EPC) = f32_to_chunk<T>(f);
+            }
+        }
+    }
+}
+
+// One wave per row; the row lives in registers between the mean and the centred-variance pass.
+template <typename T, int SLOTS>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
+                                                        int rows, int c, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunks = c / EPC;
+    float f[SLOTS][EPC];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+        const int chunk = lane + k * 64;
+        if (chunk < nchunks) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(x + (long)row * ldx + chunk * EPC);
+            chunk_to_f32<T>(v, f[k]);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) sum += f[k][e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) f[k][e] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)c;
+    float var = 0.f;
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+        const int chunk = lane + k * 64;
+        if (chunk < nchunks) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float d = f[k][e] - mean;
+                var = fmaf(d, d, var);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) var += __shfl_xor(var, o);
+    const float rstd = 1.0f / sqrtf(var / (float)c + eps);
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+        const int chunk = lane + k * 64;
+        if (chunk < nchunks) {
+            float o[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int ch = chunk * EPC + e;
+                o[e] = (f[k][e] - mean) * rstd * gamma[ch] + beta[ch];
+            }
+            *reinterpret_cast<u32x4*>(y + (long)row * ldy + chunk * EPC) = f32_to_chunk<T>(o);
+        }
+    }
+}
+
+template <typename T> int gn_stats_launch(const void* x, long ldx, int batch, int hw, int c, int groups, float* partial,
+                                          int nsplit, hipStream_t s) {
+    const GnGeom g = gn_geom<T>(c);
+    if (g.slots > GN_MAX_SLOTS) return DM_ERR_ARG;
+    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(nsplit, batch), dim3(GN_THREADS), 0, s, static_cast<const T*>(x), ldx, hw,
+                       c, groups, partial, nsplit);
+    return dm_check_launch();
+}
+
+template <typename T>
+int gn_apply_launch(const void* x, long ldx, void* y, long ldy, int batch, int hw, int c, int groups,
+                    const float* partial, int nsplit, const float* gamma, const float* beta, float eps, int silu,
+                    hipStream_t s) {
+    const GnGeom g = gn_geom<T>(c);
+    if (g.slots > GN_MAX_SLOTS || c > GN_MAX_C) return DM_ERR_ARG;
+    // enough blocks to fill the chip, at least rpi rows each
+    int want = (2048 + batch - 1) / batch;
+    int rows_per_block = (hw + want - 1) / want;
+    if (rows_per_block < g.rpi) rows_per_block = g.rpi;
+    const int nb = (hw + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(nb, batch), dim3(GN_THREADS), 3 * c * sizeof(float), s,
+                       static_cast<const T*>(x), ldx, static_cast<T*>(y), ldy, hw, c, groups, partial, nsplit, gamma,
+                       beta, eps, silu, rows_per_block);
+    return dm_check_launch();
+}
+
+template <typename T>
+int ln_launch(const void* x, long ldx, void* y, long ldy, int rows, int c, const float* gamma, const float* beta,
+              float eps, hipStream_t s) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    const int slots = (c / EPC + 63) / 64;
+    const dim3 grid((rows + 3) / 4), block(256);
+    const T* xp = static_cast<const T*>(x);
+    T* yp = static_cast<T*>(y);
+#define LN_CASE(S)                                                                                                  \
+    case S:                                                                                                         \
+        hipLaunchKernelGGL((layernorm_kernel<T, S>), grid, block, 0, s, xp, ldx, yp, ldy, rows, c, gamma, beta, eps); \
+        break;
+    switch (slots) {
+        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
+        default: return DM_ERR_ARG;
+    }
+#undef LN_CASE
+    return dm_check_launch();
+}
+
+bool norm_args_ok(const void* x, long ldx, const void* y, long ldy, int c, int dtype) {
+    const int epc = dtype == DM_F32 ? 4 : 8;
+    return x && (dtype == DM_F32 || dtype == DM_BF16) && c > 0 && c % epc == 0 && ldx % epc == 0 && dm_aligned16(x) &&
+           (!y || (ldy % epc == 0 && dm_aligned16(y)));
+}
+
+}  // namespace
+
+extern "C" int dm_groupnorm_stats(const void* x, long ldx, int batch, int hw, int c, int groups, int dtype,
+                                  float* partial, int nsplit, hipStream_t stream) {
+    if (!norm_args_ok(x, ldx, nullptr, 0, c, dtype) || !partial || batch <= 0 || hw <= 0 || groups <= 0 ||
+        groups > 64 || c % groups || nsplit <= 0 || nsplit > hw)
+        return DM_ERR_ARG;
+    return dtype == DM_F32 ? gn_stats_launch<float>(x, ldx, batch, hw, c, groups, partial, nsplit, stream)
+                           : gn_stats_launch<bf16_t>(x, ldx, batch, hw, c, groups, partial, nsplit, stream);
+}
+
+extern "C" int dm_groupnorm_apply(const void* x, long ldx, void* y, long ldy, int batch, int hw, int c, int groups,
+                                  int dtype, const float* partial, int nsplit, const float* gamma, const float* beta,
+                                  float eps, int silu, hipStream_t stream) {
+    if (!norm_args_ok(x, ldx, y, ldy, c, dtype) || !y || !partial || !gamma || !beta || batch <= 0 || hw <= 0 ||
+        groups <= 0 || groups > 64 || c % groups || nsplit <= 0)
+        return DM_ERR_ARG;
+    return dtype == DM_F32
+               ? gn_apply_launch<float>(x, ldx, y, ldy, batch, hw, c, groups, partial, nsplit, gamma, beta, eps, silu, stream)
+               : gn_apply_launch<bf16_t>(x, ldx, y, ldy, batch, hw, c, groups, partial, nsplit, gamma, beta, eps, silu, stream);
+}
+
+extern "C" int dm_layernorm(const void* x, long ldx, void* y, long ldy, int rows, int c, int dtype, const float* gamma,
+                            const float* beta, float eps, hipStream_t stream) {
+    if (!norm_args_ok(x, ldx, y, ldy, c, dtype) || !y || !gamma || !beta || rows <= 0) return DM_ERR_ARG;
+    return dtype == DM_F32 ? ln_launch<float>(x, ldx, y, ldy, rows, c, gamma, beta, eps, stream)
+                           : ln_launch<bf16_t>(x, ldx, y, ldy, rows, c, gamma, beta, eps, stream);
+}

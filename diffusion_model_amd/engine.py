@@ -1,0 +1,348 @@
+"""Host-side driver of the HIP kernels: memory arena, weight packing and per-operator launch wrappers.
+
+Everything here is plumbing around ``libdm_hip.so``: torch tensors are used only as device
+memory (``data_ptr``) and for one-time weight re-layout; all arithmetic of the hot path runs in
+the hand-written kernels.  Activations are 2-D row-major views ``[rows, C]`` (row = (batch, y, x)
+or (batch, token)) with an arbitrary row stride, which lets producers write straight into the
+channel slices of the U-Net's skip-concatenation buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, check
+
+_DM = {torch.float32: _lib.DM_F32, torch.bfloat16: _lib.DM_BF16}
+
+
+def _rup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class Arena:
+    """Bump allocator over one device buffer; deterministic addresses so launches can be graph-captured."""
+
+    def __init__(self, device, nbytes: int = 256 << 20):
+        self.device = device
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.off = 0
+        self.peak = 0
+        self.frozen = False  # set while a hipGraph capture is in progress (no regrowth allowed)
+        self._old = []       # previous buffers kept alive while views into them may still be in use
+
+    def reset(self):
+        self.off = 0
+        self._old.clear()
+
+    def mark(self) -> int:
+        return self.off
+
+    def release(self, mark: int):
+        self.off = mark
+
+    def alloc(self, rows: int, cols: int, dtype: torch.dtype) -> torch.Tensor:
+        esz = 4 if dtype in (torch.float32, torch.int32) else 2
+        nbytes = _rup(rows * cols * esz, 256)
+        if self.off + nbytes > self.buf.numel():
+            if self.frozen:
+                raise RuntimeError("arena exhausted during graph capture; run one eager step first")
+            self._old.append(self.buf)
+            self.buf = torch.empty(max(2 * self.buf.numel(), self.off + nbytes), dtype=torch.uint8, device=self.device)
+            # earlier views stay valid in the old buffer; continue in the new one at the same offset
+        t = self.buf[self.off:self.off + rows * cols * esz].view(dtype).view(rows, cols)
+        self.off += nbytes
+        self.peak = max(self.peak, self.off)
+        return t
+
+
+class PackedWeight:
+    """Weight matrix in the GEMM kernel's layout plus its fp32 bias."""
+    __slots__ = ("w", "n", "k", "npad", "kpad", "bias", "geglu", "conv_cin")
+
+    def __init__(self, w, n, k, npad, kpad, bias, geglu=False, conv_cin=0):
+        self.w, self.n, self.k, self.npad, self.kpad = w, n, k, npad, kpad
+        self.bias, self.geglu, self.conv_cin = bias, geglu, conv_cin
+
+
+class Engine:
+    """One per (device, compute dtype).  ``dtype`` float32 = exact-fp32 MFMA mode, bfloat16 = bf16 MFMA mode."""
+
+    _instances: Dict[Tuple[str, torch.dtype], "Engine"] = {}
+
+    @classmethod
+    def get(cls, device, dtype: torch.dtype) -> "Engine":
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(
+                "diffusion_model_amd runs on the HIP device only (tensor on %s); there is no CPU path" % device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if dtype not in _DM:
+            raise RuntimeError(f"unsupported compute dtype {dtype}; use float32 or bfloat16")
+        key = (str(device), dtype)
+        if key not in cls._instances:
+            cls._instances[key] = Engine(device, dtype)
+        return cls._instances[key]
+
+    def __init__(self, device, dtype):
+        self.lib = _lib.lib()
+        self.device, self.dtype = device, dtype
+        self.dm = _DM[dtype]
+        self.esz = 4 if dtype == torch.float32 else 2
+        self.epc = 16 // self.esz
+        self.bk = 8 * self.epc
+        self.arena = Arena(device)
+        self.ws = torch.empty(64 << 20, dtype=torch.uint8, device=device)  # split-K slabs
+        self.profile: Optional[dict] = None  # kernel class -> [events...] when profiling
+        self._order_cache: Dict[Tuple[int, int, bool], torch.Tensor] = {}
+        self.tile_override: Optional[Tuple[int, int]] = None
+
+    # ------------------------------------------------------------------ utilities
+    @property
+    def stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _prof(self, klass: str, work: float):
+        """Context manager timing one launch group with HIP events when profiling is on."""
+        return _Timed(self, klass, work) if self.profile is not None else _NULLCTX
+
+    def new(self, rows, cols, dtype=None, persistent=False) -> torch.Tensor:
+        dtype = dtype or self.dtype
+        if persistent:
+            return torch.empty(rows, cols, dtype=dtype, device=self.device)
+        return self.arena.alloc(rows, cols, dtype)
+
+    # ------------------------------------------------------------------ weight packing
+    def _order(self, n: int, npad: int, geglu: bool) -> torch.Tensor:
+        key = (n, npad, geglu)
+        if key not in self._order_cache:
+            arr = (C.c_int * npad)()
+            check(self.lib.dm_pack_weight_order(n, npad, int(geglu), arr), "pack_weight_order")
+            self._order_cache[key] = torch.tensor(list(arr), dtype=torch.long, device=self.device)
+        return self._order_cache[key]
+
+    def pack_matrix(self, w2d: torch.Tensor, bias: Optional[torch.Tensor], geglu=False, conv_cin=0) -> PackedWeight:
+        n, k = w2d.shape
+        npad, kpad = _rup(n, 128), _rup(k, self.bk)  # widest block tile is 128 columns
+        order = self._order(n, npad, geglu)
+        wp = torch.zeros(npad, kpad, dtype=self.dtype, device=self.device)
+        valid = order >= 0
+        wp[valid, :k] = w2d.detach().to(self.device)[order[valid]].to(self.dtype)
+        b = None if bias is None else bias.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        return PackedWeight(wp, n, k, npad, kpad, b, geglu, conv_cin)
+
+    def pack_linear(self, lin: torch.nn.Linear, geglu=False) -> PackedWeight:
+        return self.pack_matrix(lin.weight, lin.bias, geglu)
+
+    def pack_conv1x1(self, conv: torch.nn.Conv2d) -> PackedWeight:
+        return self.pack_matrix(conv.weight.reshape(conv.out_channels, conv.in_channels), conv.bias)
+
+    def pack_conv3x3(self, conv: torch.nn.Conv2d) -> PackedWeight:
+        w = conv.weight.detach().permute(0, 2, 3, 1)  # (Cout, 3, 3, Cin): k = tap*Cin + c
+        cin = conv.in_channels
+        cpad = _rup(cin, 8)
+        if cpad != cin:
+            w = torch.nn.functional.pad(w, (0, cpad - cin))
+        return self.pack_matrix(w.reshape(conv.out_channels, 9 * cpad), conv.bias, conv_cin=cpad)
+
+    # ------------------------------------------------------------------ operators
+    def gemm(self, a: torch.Tensor, pw: PackedWeight, out: Optional[torch.Tensor] = None, *, bias=True,
+             rowbias: Optional[torch.Tensor] = None, rows_per_batch: int = 0, residual: Optional[torch.Tensor] = None,
+             conv: Optional[dict] = None, nchw_out: Optional[torch.Tensor] = None, persistent=False) -> torch.Tensor:
+        d = GemmDesc()
+        if conv is not None:
+            m = conv["batch"] * conv["hout"] * conv["wout"]
+            d.conv, d.hin, d.win, d.hout, d.wout = 1, conv["hin"], conv["win"], conv["hout"], conv["wout"]
+            d.cin, d.stride, d.up = pw.conv_cin, conv.get("stride", 1), conv.get("up", 0)
+            if a.shape[1] != pw.conv_cin:
+                raise RuntimeError("conv input channel mismatch")
+            klass = "conv3x3"
+        else:
+            m = a.shape[0]
+            if a.shape[1] != pw.k:
+                raise RuntimeError(f"GEMM inner dimension mismatch: {a.shape[1]} vs {pw.k}")
+            klass = "gemm"
+        n_out = pw.n // 2 if pw.geglu else pw.n
+        if nchw_out is not None:
+            d.c, d.ldc, d.epi = nchw_out.data_ptr(), 0, _lib.EPI_NCHW_F32
+            out = nchw_out
+        else:
+            if out is None:
+                out = self.new(m, n_out, persistent=persistent)
+            d.c, d.ldc = out.data_ptr(), out.stride(0)
+            d.epi = _lib.EPI_GEGLU if pw.geglu else _lib.EPI_PLAIN
+        d.a, d.lda = a.data_ptr(), a.stride(0)
+        d.w = pw.w.data_ptr()
+        d.bias = pw.bias.data_ptr() if (bias and pw.bias is not None) else None
+        if rowbias is not None:
+            d.rowbias, d.ld_rowbias = rowbias.data_ptr(), rowbias.stride(0)
+        d.rows_per_batch = rows_per_batch
+        if residual is not None:
+            d.r, d.ldr = residual.data_ptr(), residual.stride(0)
+        d.m, d.n, d.k, d.npad, d.kpad, d.dtype = m, pw.n, pw.k, pw.npad, pw.kpad, self.dm
+        tile, sk = C.c_int(0), C.c_int(1)
+        if self.tile_override is not None:
+            tile.value, sk.value = self.tile_override
+            if d.epi != _lib.EPI_PLAIN:
+                sk.value = 1
+        else:
+            self.lib.dm_gemm_plan(self.dm, m, pw.n, pw.k, d.epi, C.byref(tile), C.byref(sk))
+        d.tile, d.splitk = tile.value, sk.value
+        if sk.value > 1:
+            need = self.lib.dm_gemm_workspace_bytes(m, pw.n, sk.value)
+            if need > self.ws.numel():
+                if self.arena.frozen:
+                    raise RuntimeError("split-K workspace too small during graph capture")
+                self.ws = torch.empty(need * 2, dtype=torch.uint8, device=self.device)
+            d.workspace, d.workspace_bytes = self.ws.data_ptr(), self.ws.numel()
+        with self._prof(klass, 2.0 * m * pw.n * (pw.k if conv is None else 9 * conv["cin_real"])):
+            check(self.lib.dm_gemm(C.byref(d), self.stream), klass)
+        return out
+
+    def groupnorm(self, x: torch.Tensor, batch: int, hw: int, gamma, beta, eps: float, silu: bool,
+                  out: Optional[torch.Tensor] = None, groups: int = 32) -> torch.Tensor:
+        c = x.shape[1]
+        if out is None:
+            out = self.new(batch * hw, c)
+        nsplit = max(1, min(hw // 8, (512 + batch - 1) // batch, 64))
+        part = self.arena.alloc(batch * nsplit, groups * 2, torch.float32)
+        with self._prof("groupnorm", float(batch * hw * c * self.esz * 2)):
+            check(self.lib.dm_groupnorm_stats(x.data_ptr(), x.stride(0), batch, hw, c, groups, self.dm,
+                                              part.data_ptr(), nsplit, self.stream), "groupnorm_stats")
+            check(self.lib.dm_groupnorm_apply(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), batch, hw, c,
+                                              groups, self.dm, part.data_ptr(), nsplit, gamma.data_ptr(),
+                                              beta.data_ptr(), eps, int(silu), self.stream), "groupnorm_apply")
+        return out
+
+    def layernorm(self, x: torch.Tensor, gamma, beta, eps: float = 1e-5, out=None) -> torch.Tensor:
+        rows, c = x.shape
+        if out is None:
+            out = self.new(rows, c)
+        with self._prof("layernorm", float(rows * c * self.esz * 2)):
+            check(self.lib.dm_layernorm(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), rows, c, self.dm,
+                                        gamma.data_ptr(), beta.data_ptr(), eps, self.stream), "layernorm")
+        return out
+
+    def transpose_v(self, v: torch.Tensor, batch: int, s: int, heads: int, d: int, persistent=False, out=None):
+        ldv = _rup(s, 64)
+        vt = out if out is not None else self.new(batch * heads * d, ldv, persistent=persistent)
+        with self._prof("transpose_v", float(batch * s * heads * d * self.esz * 2)):
+            check(self.lib.dm_transpose_v(v.data_ptr(), v.stride(0), batch, s, heads, d, vt.data_ptr(), ldv, self.dm,
+                                          self.stream), "transpose_v")
+        return vt
+
+    def attention(self, q, k, vt, batch, heads, sq, sk, d, out=None) -> torch.Tensor:
+        if out is None:
+            out = self.new(batch * sq, heads * d)
+        with self._prof("attention", 4.0 * batch * heads * sq * sk * d):
+            check(self.lib.dm_attention(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), vt.data_ptr(),
+                                        vt.stride(0), out.data_ptr(), out.stride(0), batch, heads, sq, sk, d, self.dm,
+                                        self.stream), "attention")
+        return out
+
+    def linear_rows(self, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], silu_in: bool,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        batch, k = x.shape
+        n = w.shape[0]
+        if out is None:
+            out = self.arena.alloc(batch, n, torch.float32)
+        with self._prof("time_linear", float(n * k * 4)):
+            check(self.lib.dm_linear_rows(x.data_ptr(), x.stride(0), w.data_ptr(), b.data_ptr() if b is not None else None,
+                                          out.data_ptr(), out.stride(0), batch, n, k, int(silu_in), self.stream),
+                  "linear_rows")
+        return out
+
+    def nchw_to_rows(self, x: torch.Tensor, cpad: Optional[int] = None, out=None) -> torch.Tensor:
+        b, c, h, w = x.shape
+        cpad = cpad or c
+        x = x.contiguous()
+        if x.dtype != torch.float32:
+            x = x.float()
+        if out is None:
+            out = self.new(b * h * w, cpad)
+        check(self.lib.dm_nchw_to_rows(x.data_ptr(), b, c, h * w, out.data_ptr(), out.stride(0), cpad, self.dm,
+                                       self.stream), "nchw_to_rows")
+        return out
+
+    def rows_to_nchw(self, rows: torch.Tensor, b: int, c: int, h: int, w: int, out=None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty(b, c, h, w, dtype=torch.float32, device=self.device)
+        check(self.lib.dm_rows_to_nchw(rows.data_ptr(), rows.stride(0), b, c, h * w, out.data_ptr(), self.dm,
+                                       self.stream), "rows_to_nchw")
+        return out
+
+    def to_rows(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, S, C) fp32/bf16 tensor -> engine-dtype [B*S, C] rows (arena)."""
+        b, s, c = x.shape
+        x = x.contiguous()
+        if x.dtype == self.dtype:
+            return x.view(b * s, c)
+        out = self.new(b * s, c)
+        if x.dtype != torch.float32:
+            x = x.float()
+        if self.dtype == torch.float32:
+            return x.view(b * s, c)
+        check(self.lib.dm_convert(x.data_ptr(), _lib.DM_F32, out.data_ptr(), self.dm, b * s * c, self.stream), "convert")
+        return out
+
+    def from_rows(self, rows: torch.Tensor, shape) -> torch.Tensor:
+        """engine-dtype contiguous rows -> new fp32 torch tensor of ``shape``."""
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        n = out.numel()
+        if self.dtype == torch.float32:
+            out.view(-1).copy_(rows.reshape(-1))
+        else:
+            check(self.lib.dm_convert(rows.data_ptr(), self.dm, out.data_ptr(), _lib.DM_F32, n, self.stream), "convert")
+        return out
+
+    # ------------------------------------------------------------------ profiling
+    def start_profile(self):
+        self.profile = {}
+
+    def stop_profile(self) -> Dict[str, dict]:
+        """Synchronise and return {class: {"ms": total, "launches": n, "work": sum}}."""
+        prof, self.profile = self.profile, None
+        out = {}
+        ms = C.c_float()
+        for klass, items in prof.items():
+            tot, work = 0.0, 0.0
+            for e0, e1, w in items:
+                check(self.lib.dm_event_elapsed_ms(e0, e1, C.byref(ms)), "event_elapsed")
+                tot += ms.value
+                work += w
+                self.lib.dm_event_destroy(e0)
+                self.lib.dm_event_destroy(e1)
+            out[klass] = {"ms": tot, "launches": len(items), "work": work}
+        return out
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULLCTX = _Null()
+
+
+class _Timed:
+    def __init__(self, eng: Engine, klass: str, work: float):
+        self.eng, self.klass, self.work = eng, klass, work
+
+    def __enter__(self):
+        self.e0, self.e1 = C.c_void_p(), C.c_void_p()
+        check(self.eng.lib.dm_event_create(C.byref(self.e0)), "event_create")
+        check(self.eng.lib.dm_event_create(C.byref(self.e1)), "event_create")
+        check(self.eng.lib.dm_event_record(self.e0, self.eng.stream), "event_record")
+        return self
+
+    def __exit__(self, *a):
+        check(self.eng.lib.dm_event_record(self.e1, self.eng.stream), "event_record")
+        self.eng.profile.setdefault(self.klass, []).append((self.e0, self.e1, self.work))
+        return False

@@ -1,0 +1,9 @@
+"""Drop-in counterparts of the reference's ``src/models`` classes for the denoising path."""
+from .attention import CrossAttention, SelfAttention
+from .blocks import AttentionBlock, ResidualBlock
+from .diffusion import Diffusion, FinalLayer
+from .embeddings import TimeEmbedding
+from .unet import SwitchSequential, UNet, Upsample
+
+__all__ = ["SelfAttention", "CrossAttention", "ResidualBlock", "AttentionBlock", "TimeEmbedding",
+           "Upsample", "SwitchSequential", "UNet", "FinalLayer", "Diffusion"]

@@ -1,0 +1,330 @@
+"""Execution of the noise predictor on the HIP engine: weight packs and block runners.
+
+The ``nn.Module`` classes in ``diffusion_model_amd.models`` only hold parameters (so state_dicts stay
+interchangeable with the reference); their ``forward`` methods call the functions below, which
+issue the kernel launches.  Mapping to the reference's forward passes:
+
+  run_residual_block  <- ResidualBlock.forward   (src/models/blocks.py:44-72)
+  run_attention_block <- AttentionBlock.forward  (src/models/blocks.py:114-159)
+  run_unet            <- UNet.forward            (src/models/unet.py:148-175)
+  diffusion_forward   <- Diffusion.forward       (src/models/diffusion.py:73-101)
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace as NS
+from typing import List, Optional
+
+import torch
+
+from .engine import Engine, _rup
+
+
+# ----------------------------------------------------------------------------------------------
+# packing
+# ----------------------------------------------------------------------------------------------
+def _f32(eng: Engine, p: torch.Tensor) -> torch.Tensor:
+    return p.detach().to(device=eng.device, dtype=torch.float32).contiguous()
+
+
+def module_dtype(module: torch.nn.Module) -> torch.dtype:
+    for p in module.parameters():
+        return p.dtype
+    raise RuntimeError("module has no parameters")
+
+
+def _signature(module: torch.nn.Module):
+    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+
+
+def cached_pack(module: torch.nn.Module, eng: Engine, builder):
+    """Pack once per (engine, parameter version); repack if any parameter was modified in place or moved."""
+    cache = module.__dict__.setdefault("_dm_pack_cache", {})
+    sig = _signature(module)
+    hit = cache.get(id(eng))
+    if hit is None or hit[0] != sig:
+        hit = (sig, builder(module, eng))
+        cache[id(eng)] = hit
+    return hit[1]
+
+
+def pack_residual_block(m, eng: Engine) -> NS:
+    cin, cout = m.conv_feature.in_channels, m.conv_feature.out_channels
+    return NS(kind="res", cin=cin, cout=cout,
+              gn1_w=_f32(eng, m.groupnorm_feature.weight), gn1_b=_f32(eng, m.groupnorm_feature.bias),
+              gn1_eps=m.groupnorm_feature.eps,
+              conv1=eng.pack_conv3x3(m.conv_feature),
+              lt_w=_f32(eng, m.linear_time.weight), lt_b=_f32(eng, m.linear_time.bias),
+              gn2_w=_f32(eng, m.groupnorm_merged.weight), gn2_b=_f32(eng, m.groupnorm_merged.bias),
+              gn2_eps=m.groupnorm_merged.eps,
+              conv2=eng.pack_conv3x3(m.conv_merged),
+              res=None if isinstance(m.residual_layer, torch.nn.Identity) else eng.pack_conv1x1(m.residual_layer),
+              t_off=0)
+
+
+def pack_self_attention(m, eng: Engine) -> NS:
+    return NS(heads=m.n_heads, d=m.d_head, in_proj=eng.pack_linear(m.in_proj), out_proj=eng.pack_linear(m.out_proj))
+
+
+def pack_cross_attention(m, eng: Engine) -> NS:
+    return NS(heads=m.n_heads, d=m.d_head, q_proj=eng.pack_linear(m.q_proj), k_proj=eng.pack_linear(m.k_proj),
+              v_proj=eng.pack_linear(m.v_proj), out_proj=eng.pack_linear(m.out_proj))
+
+
+def pack_attention_block(m, eng: Engine) -> NS:
+    c = m.conv_input.in_channels
+    return NS(kind="attn", c=c,
+              gn_w=_f32(eng, m.group_norm.weight), gn_b=_f32(eng, m.group_norm.bias), gn_eps=m.group_norm.eps,
+              conv_in=eng.pack_conv1x1(m.conv_input),
+              ln1_w=_f32(eng, m.layer_norm_1.weight), ln1_b=_f32(eng, m.layer_norm_1.bias), ln1_eps=m.layer_norm_1.eps,
+              sa=pack_self_attention(m.attention_1, eng),
+              ln2_w=_f32(eng, m.layer_norm_2.weight), ln2_b=_f32(eng, m.layer_norm_2.bias), ln2_eps=m.layer_norm_2.eps,
+              ca=pack_cross_attention(m.attention_2, eng),
+              ln3_w=_f32(eng, m.layer_norm_3.weight), ln3_b=_f32(eng, m.layer_norm_3.bias), ln3_eps=m.layer_norm_3.eps,
+              geglu1=eng.pack_linear(m.linear_geglu_1, geglu=True),
+              geglu2=eng.pack_linear(m.linear_geglu_2),
+              conv_out=eng.pack_conv1x1(m.conv_output))
+
+
+def pack_conv_layer(conv: torch.nn.Conv2d, eng: Engine, up: bool = False) -> NS:
+    return NS(kind="up" if up else "conv", cin=conv.in_channels, cout=conv.out_channels, stride=conv.stride[0],
+              w=eng.pack_conv3x3(conv))
+
+
+def pack_final_layer(m, eng: Engine) -> NS:
+    return NS(gn_w=_f32(eng, m.group_norm.weight), gn_b=_f32(eng, m.group_norm.bias), gn_eps=m.group_norm.eps,
+              cin=m.conv.in_channels, cout=m.conv.out_channels, conv=eng.pack_conv3x3(m.conv))
+
+
+def pack_time_embedding(m, eng: Engine) -> NS:
+    return NS(w1=_f32(eng, m.linear_1.weight), b1=_f32(eng, m.linear_1.bias),
+              w2=_f32(eng, m.linear_2.weight), b2=_f32(eng, m.linear_2.bias))
+
+
+def _pack_stage(stage, eng: Engine) -> List[NS]:
+    from .models.blocks import AttentionBlock, ResidualBlock
+    from .models.unet import Upsample
+    out = []
+    for layer in stage:
+        if isinstance(layer, AttentionBlock):
+            out.append(pack_attention_block(layer, eng))
+        elif isinstance(layer, ResidualBlock):
+            out.append(pack_residual_block(layer, eng))
+        elif isinstance(layer, Upsample):
+            out.append(pack_conv_layer(layer.conv, eng, up=True))
+        elif isinstance(layer, torch.nn.Conv2d):
+            if layer.kernel_size != (3, 3) or layer.padding != (1, 1):
+                raise RuntimeError("only 3x3 / padding-1 convolutions are supported inside the U-Net")
+            out.append(pack_conv_layer(layer, eng))
+        else:
+            raise RuntimeError(f"unsupported layer in SwitchSequential: {type(layer).__name__}")
+    return out
+
+
+def _stage_cout(layers: List[NS], cin: int) -> int:
+    c = cin
+    for lp in layers:
+        c = lp.cout if lp.kind in ("res", "conv", "up") else c
+    return c
+
+
+def pack_unet(m, eng: Engine) -> NS:
+    pk = NS(encoders=[_pack_stage(s, eng) for s in m.encoders],
+            bottleneck=_pack_stage(m.bottleneck, eng),
+            decoders=[_pack_stage(s, eng) for s in m.decoders])
+    # all ResidualBlock time projections as one matrix: one launch per forward instead of 22
+    res = [lp for st in pk.encoders + [pk.bottleneck] + pk.decoders for lp in st if lp.kind == "res"]
+    off = 0
+    for lp in res:
+        lp.t_off = off
+        off += lp.cout
+    pk.lt_w = torch.cat([lp.lt_w for lp in res], 0).contiguous()
+    pk.lt_b = torch.cat([lp.lt_b for lp in res], 0).contiguous()
+    pk.attn = [lp for st in pk.encoders + [pk.bottleneck] + pk.decoders for lp in st if lp.kind == "attn"]
+    pk.cin = pk.encoders[0][0].cin
+    return pk
+
+
+def pack_diffusion(m, eng: Engine) -> NS:
+    return NS(te=pack_time_embedding(m.time_embedding, eng), unet=pack_unet(m.unet, eng),
+              final=pack_final_layer(m.final, eng))
+
+
+# ----------------------------------------------------------------------------------------------
+# block runners (all tensors are engine-dtype [rows, C] views unless noted)
+# ----------------------------------------------------------------------------------------------
+def run_residual_block(eng: Engine, pk: NS, x, batch: int, h: int, w: int, tproj, out=None):
+    """tproj: fp32 (batch, cout) view holding linear_time(silu(time))."""
+    hw = h * w
+    if out is None:
+        out = eng.new(batch * hw, pk.cout)
+    mark = eng.arena.mark()
+    geom = dict(batch=batch, hin=h, win=w, hout=h, wout=w)
+    a = eng.groupnorm(x, batch, hw, pk.gn1_w, pk.gn1_b, pk.gn1_eps, silu=True)
+    a = eng.gemm(a, pk.conv1, rowbias=tproj, rows_per_batch=hw, conv=dict(geom, cin_real=pk.cin))
+    a = eng.groupnorm(a, batch, hw, pk.gn2_w, pk.gn2_b, pk.gn2_eps, silu=True)
+    skip = x if pk.res is None else eng.gemm(x, pk.res)
+    eng.gemm(a, pk.conv2, out=out, residual=skip, conv=dict(geom, cin_real=pk.cout))
+    eng.arena.release(mark)
+    return out
+
+
+def context_kv(eng: Engine, ca: NS, ctx_rows, batch: int, sk: int, persistent=False, out=None):
+    """K rows and per-head transposed V of the conditioning sequence for one cross-attention.
+
+    ``out`` = (k, vt) buffers from an earlier call to refill in place (addresses baked into a captured graph).
+    """
+    k = eng.gemm(ctx_rows, ca.k_proj, out=None if out is None else out[0], persistent=persistent)
+    v = eng.gemm(ctx_rows, ca.v_proj)
+    vt = eng.transpose_v(v, batch, sk, ca.heads, ca.d, persistent=persistent, out=None if out is None else out[1])
+    return k, vt
+
+
+def run_self_attention(eng: Engine, sa: NS, x, batch: int, s: int, out=None, residual=None):
+    c = sa.heads * sa.d
+    qkv = eng.gemm(x, sa.in_proj)
+    vt = eng.transpose_v(qkv[:, 2 * c:3 * c], batch, s, sa.heads, sa.d)
+    o = eng.attention(qkv[:, 0:c], qkv[:, c:2 * c], vt, batch, sa.heads, s, s, sa.d)
+    return eng.gemm(o, sa.out_proj, out=out, residual=residual)
+
+
+def run_cross_attention(eng: Engine, ca: NS, x, kv, batch: int, s: int, sk: int, out=None, residual=None):
+    q = eng.gemm(x, ca.q_proj)
+    o = eng.attention(q, kv[0], kv[1], batch, ca.heads, s, sk, ca.d)
+    return eng.gemm(o, ca.out_proj, out=out, residual=residual)
+
+
+def run_attention_block(eng: Engine, pk: NS, x, batch: int, h: int, w: int, kv, sk: int, out=None):
+    s = h * w
+    if out is None:
+        out = eng.new(batch * s, pk.c)
+    mark = eng.arena.mark()
+    a = eng.groupnorm(x, batch, s, pk.gn_w, pk.gn_b, pk.gn_eps, silu=False)
+    t = eng.gemm(a, pk.conv_in)
+    a = eng.layernorm(t, pk.ln1_w, pk.ln1_b, pk.ln1_eps)
+    t = run_self_attention(eng, pk.sa, a, batch, s, residual=t)
+    a = eng.layernorm(t, pk.ln2_w, pk.ln2_b, pk.ln2_eps)
+    t = run_cross_attention(eng, pk.ca, a, kv, batch, s, sk, residual=t)
+    a = eng.layernorm(t, pk.ln3_w, pk.ln3_b, pk.ln3_eps)
+    a = eng.gemm(a, pk.geglu1)
+    t = eng.gemm(a, pk.geglu2, residual=t)
+    eng.gemm(t, pk.conv_out, out=out, residual=x)
+    eng.arena.release(mark)
+    return out
+
+
+def _conv_out_hw(lp: NS, h: int, w: int):
+    if lp.kind == "up":
+        return 2 * h, 2 * w
+    return (h + 2 - 3) // lp.stride + 1, (w + 2 - 3) // lp.stride + 1
+
+
+def run_conv_layer(eng: Engine, lp: NS, x, batch: int, h: int, w: int, out=None):
+    ho, wo = _conv_out_hw(lp, h, w)
+    geom = dict(batch=batch, hin=h, win=w, hout=ho, wout=wo, stride=lp.stride, up=int(lp.kind == "up"),
+                cin_real=lp.cin)
+    return eng.gemm(x, lp.w, out=out, conv=geom), ho, wo
+
+
+def _run_stage(eng: Engine, layers: List[NS], x, batch, h, w, tproj, kvs, sk, out):
+    """Run one SwitchSequential; the last layer writes into ``out`` (e.g. a concat-buffer slice)."""
+    if out is None:  # allocate the result before the scope mark so it survives the release below
+        c2, h2, w2 = _stage_shape(layers, x.shape[1], h, w)
+        out = eng.new(batch * h2 * w2, c2)
+    mark = eng.arena.mark()
+    for i, lp in enumerate(layers):
+        dst = out if i == len(layers) - 1 else None
+        if lp.kind == "res":
+            x = run_residual_block(eng, lp, x, batch, h, w, tproj[:, lp.t_off:lp.t_off + lp.cout], out=dst)
+        elif lp.kind == "attn":
+            x = run_attention_block(eng, lp, x, batch, h, w, kvs[id(lp)], sk, out=dst)
+        else:
+            x, h, w = run_conv_layer(eng, lp, x, batch, h, w, out=dst)
+    eng.arena.release(mark)
+    return x, h, w
+
+
+def _stage_shape(layers: List[NS], c: int, h: int, w: int):
+    for lp in layers:
+        if lp.kind in ("conv", "up"):
+            h, w = _conv_out_hw(lp, h, w)
+        c = lp.cout if lp.kind != "attn" else c
+    return c, h, w
+
+
+def run_unet(eng: Engine, pk: NS, x, batch: int, h: int, w: int, tproj, kvs, sk: int):
+    """x: [batch*h*w, cin_padded] rows.  Returns ([batch*h*w, 320] rows, h, w).
+
+    The reference's ``torch.cat((x, skip))`` never happens: for every decoder stage one buffer
+    [rows, C_x + C_skip] is laid out up front; the encoder stage that produces the skip writes it
+    into the right-hand channel slice and the preceding decoder stage writes x into the left one.
+    """
+    n = len(pk.encoders)
+    # shapes of the encoder outputs
+    shapes = []
+    c, hh, ww = pk.cin, h, w
+    for st in pk.encoders:
+        c, hh, ww = _stage_shape(st, c, hh, ww)
+        shapes.append((c, hh, ww))
+    # decoder inputs: x channels come from the bottleneck / previous decoder stage
+    cx, hx, wx = _stage_shape(pk.bottleneck, *shapes[-1])
+    cat = []
+    for i, st in enumerate(pk.decoders):
+        cs, hs, ws = shapes[n - 1 - i]
+        if (hs, ws) != (hx, wx):
+            raise RuntimeError(f"skip connection size mismatch at decoder {i}: {(hx, wx)} vs {(hs, ws)}; "
+                               "latent height/width must be divisible by 8")
+        cat.append((eng.new(batch * hs * ws, cx + cs), cx, cs))
+        cx, hx, wx = _stage_shape(st, cx + cs, hs, ws)
+
+    hh, ww = h, w
+    for j, st in enumerate(pk.encoders):
+        buf, cxj, csj = cat[n - 1 - j]
+        x, hh, ww = _run_stage(eng, st, x, batch, hh, ww, tproj, kvs, sk, out=buf[:, cxj:cxj + csj])
+    buf0, cx0, _ = cat[0]
+    x, hh, ww = _run_stage(eng, pk.bottleneck, x, batch, hh, ww, tproj, kvs, sk, out=buf0[:, 0:cx0])
+    for i, st in enumerate(pk.decoders):
+        buf = cat[i][0]
+        if i + 1 < len(pk.decoders):
+            nbuf, ncx, _ = cat[i + 1]
+            dst = nbuf[:, 0:ncx]
+        else:
+            dst = None
+        x, hh, ww = _run_stage(eng, st, buf, batch, hh, ww, tproj, kvs, sk, out=dst)
+    return x, hh, ww
+
+
+def precompute_context(eng: Engine, pk_unet: NS, context: torch.Tensor, persistent=False, out=None):
+    """Cross-attention K / V^T of every AttentionBlock for a fixed conditioning tensor (B, S, 768).
+
+    These 32 projections do not depend on the latent or the timestep, so a sampling loop computes
+    them once (``persistent=True`` keeps them outside the per-forward arena; ``out`` refills the
+    buffers of an earlier call).
+    """
+    batch, sk, _ = context.shape
+    mark = eng.arena.mark()
+    rows = eng.to_rows(context)
+    kvs = {}
+    for lp in pk_unet.attn:
+        m2 = eng.arena.mark()
+        kvs[id(lp)] = context_kv(eng, lp.ca, rows, batch, sk, persistent, None if out is None else out[id(lp)])
+        if persistent or out is not None:
+            eng.arena.release(m2)
+    if persistent or out is not None:
+        eng.arena.release(mark)
+    return kvs, sk
+
+
+def diffusion_forward_into(eng: Engine, pk: NS, latent_f32: torch.Tensor, time_f32: torch.Tensor, kvs, sk: int,
+                           eps_out: torch.Tensor):
+    """Launch-only body (no torch allocation): latent (B,4,H,W) fp32, time (B,320) fp32 -> eps_out (B,4,H,W) fp32."""
+    batch, cin, h, w = latent_f32.shape
+    hw = h * w
+    t = eng.linear_rows(time_f32, pk.te.w1, pk.te.b1, silu_in=False)
+    t = eng.linear_rows(t, pk.te.w2, pk.te.b2, silu_in=True)
+    tproj = eng.linear_rows(t, pk.unet.lt_w, pk.unet.lt_b, silu_in=True)
+    x = eng.nchw_to_rows(latent_f32, cpad=_rup(cin, 8))
+    x, ho, wo = run_unet(eng, pk.unet, x, batch, h, w, tproj, kvs, sk)
+    a = eng.groupnorm(x, batch, hw, pk.final.gn_w, pk.final.gn_b, pk.final.gn_eps, silu=True)
+    eng.gemm(a, pk.final.conv, nchw_out=eps_out, rows_per_batch=hw,
+             conv=dict(batch=batch, hin=h, win=w, hout=h, wout=w, cin_real=pk.final.cin))
+    return eps_out

@@ -1,0 +1,222 @@
+"""DDPM ancestral sampler (reference: src/schedulers/ddpm_scheduler.py:18-251).
+
+``step`` is one fused HIP kernel.  ``sample`` keeps the reference's loop semantics (x_T ~ N(0, I);
+for t = T-1 .. 0: time features -> model -> step) but, when ``model`` is this package's
+``Diffusion``, runs the loop body as a captured hipGraph: the per-step scalars, time features and
+pre-drawn noise live in device tables indexed by a device-side step counter, so one graph serves
+every step and the host only replays it.
+"""
+from typing import Optional
+
+import ctypes as C
+import torch
+
+from .. import _lib, runtime as rt
+from .._lib import check
+from .base_scheduler import BaseScheduler, draw_normal, require_hip, sinusoidal_table, stream_of
+
+
+class DDPMScheduler(BaseScheduler):
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.0001, beta_end: float = 0.02,
+                 beta_schedule: str = "linear", clip_sample: bool = True, device: str = "cpu"):
+        super().__init__(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                         beta_schedule=beta_schedule, device=device)
+        self.clip_sample = clip_sample
+        self.use_hip_graph = True
+        self._coef_host = None
+        self._coef_dev = {}
+        self._loops = {}
+
+    # ---- per-timestep scalars ------------------------------------------------------------------------
+    def step_coefficients(self) -> torch.Tensor:
+        """(T, 5) fp32 CPU table, row t = [sqrt(1-acp_t), sqrt(acp_t), c_x0, c_xt, sigma_t]; sigma_0 = 0.
+
+        Evaluated with the same fp32 operations the reference applies to its 0-dim tensors
+        (ddpm_scheduler.py:89-127), so every entry is bit-identical to the reference's scalar.
+        """
+        if self._coef_host is None:
+            h = self._host
+            acp, acp_prev = h["alphas_cumprod"], h["alphas_cumprod_prev"]  # acp_prev[0] == 1.0
+            bp, bp_prev = 1 - acp, 1 - acp_prev
+            c_x0 = (acp_prev.sqrt() * h["betas"]) / bp
+            c_xt = (h["alphas"].sqrt() * bp_prev) / bp
+            sigma = h["posterior_variance"].sqrt().clone()
+            sigma[0] = 0.0
+            self._coef_host = torch.stack([bp.sqrt(), acp.sqrt(), c_x0, c_xt, sigma], dim=1).contiguous()
+        return self._coef_host
+
+    def _coef_on(self, device) -> torch.Tensor:
+        key = str(device)
+        if key not in self._coef_dev:
+            self._coef_dev[key] = self.step_coefficients().to(device)
+        return self._coef_dev[key]
+
+    # ---- one reverse step ----------------------------------------------------------------------------
+    def step(self, model_output: torch.Tensor, timestep: int, sample: torch.Tensor,
+             generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        require_hip(sample, "DDPMScheduler.step")
+        t = int(timestep)
+        x = sample.float().contiguous()
+        eps = model_output.float().contiguous()
+        noise = draw_normal(sample.shape, generator, sample.device, torch.float32) if t > 0 else None
+        out = torch.empty_like(x)
+        coef = self._coef_on(sample.device)[t]
+        check(_lib.lib().dm_ddpm_step(x.data_ptr(), eps.data_ptr(), noise.data_ptr() if noise is not None else None,
+                                      out.data_ptr(), x.numel(), coef.data_ptr(), None, int(self.clip_sample),
+                                      stream_of(sample)), "ddpm_step")
+        return out.to(sample.dtype)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        return super().add_noise(original_samples, noise, timesteps)
+
+    # ---- sampling loop -------------------------------------------------------------------------------
+    def sample(self, model: torch.nn.Module, shape: tuple, context: Optional[torch.Tensor] = None,
+               generator: Optional[torch.Generator] = None, device: str = "cpu") -> torch.Tensor:
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("DDPMScheduler.sample: device must be the HIP device ('cuda'); there is no CPU path")
+        T = self.num_train_timesteps
+        # generator consumption order of the reference: x_T, then one draw per step with t > 0
+        x_T = draw_normal(shape, generator, device)
+        noises = [draw_normal(shape, generator, device) for _ in range(T - 1)]
+        from ..models.diffusion import Diffusion
+        if isinstance(model, Diffusion) and context is not None:
+            return self.sample_from_noise(model, x_T, noises, context)
+        sample = x_T
+        for i, t in enumerate(reversed(range(T))):
+            timestep = torch.full((shape[0],), t, device=device, dtype=torch.long)
+            time_emb = self._get_timestep_embedding(timestep, embedding_dim=320)
+            with torch.no_grad():
+                noise_pred = model(sample, context, time_emb) if context is not None else model(sample, time_emb)
+            sample = self._step_with_noise(noise_pred, t, sample, noises[i] if t > 0 else None)
+        return sample
+
+    def _step_with_noise(self, eps, t, x, noise):
+        out = torch.empty_like(x)
+        coef = self._coef_on(x.device)[t]
+        check(_lib.lib().dm_ddpm_step(x.data_ptr(), eps.float().contiguous().data_ptr(),
+                                      noise.data_ptr() if noise is not None else None, out.data_ptr(), x.numel(),
+                                      coef.data_ptr(), None, int(self.clip_sample), stream_of(x)), "ddpm_step")
+        return out
+
+    @torch.no_grad()
+    def sample_from_noise(self, model, x_T: torch.Tensor, noises, context: torch.Tensor,
+                          trace: Optional[list] = None) -> torch.Tensor:
+        """Reverse loop on the HIP engine with explicit draws: ``noises[i]`` is injected at step t = T-1-i (t > 0).
+
+        ``trace``, if given, receives a copy of the latent after every step.
+        """
+        require_hip(x_T, "DDPMScheduler.sample_from_noise")
+        st = self._loop_state(model, tuple(x_T.shape), x_T.device, context.shape[1])
+        return st.run(self, model, x_T, noises, context, trace)
+
+    def _loop_state(self, model, shape, device, sk):
+        eng, _ = model.hip_pack(device)
+        key = (id(model), shape, str(device), id(eng), sk)
+        st = self._loops.get(key)
+        if st is None:
+            self._loops.clear()  # one resident loop state at a time
+            st = _DdpmLoop(self, model, shape, device, sk)
+            self._loops[key] = st
+        return st
+
+    def _get_timestep_embedding(self, timesteps: torch.Tensor, embedding_dim: int, max_period: int = 10000):
+        """(B,) timesteps -> (B, embedding_dim) sinusoidal features on the timesteps' device."""
+        if timesteps.device.type != "cuda":
+            return sinusoidal_table(timesteps, embedding_dim, max_period)
+        t = timesteps.to(torch.long).contiguous()
+        out = torch.empty(t.shape[0], embedding_dim, dtype=torch.float32, device=t.device)
+        check(_lib.lib().dm_timestep_embedding(t.data_ptr(), t.shape[0], embedding_dim, float(max_period),
+                                               out.data_ptr(), stream_of(t)), "timestep_embedding")
+        return out
+
+    def __repr__(self) -> str:
+        return (f"DDPMScheduler(num_timesteps={self.num_train_timesteps}, beta_schedule={self.beta_schedule}, "
+                f"beta_range=[{self.beta_start:.6f}, {self.beta_end:.6f}])")
+
+
+class _DdpmLoop:
+    """Persistent device state of one (model, latent shape) sampling loop and its captured step graph."""
+
+    def __init__(self, sched: DDPMScheduler, model, shape, device, sk):
+        self.lib = _lib.lib()
+        self.shape, self.device = shape, device
+        T = sched.num_train_timesteps
+        self.T = T
+        self.eng, self.pk = model.hip_pack(device)
+        self.sig = rt._signature(model)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.x = torch.empty(shape, **f32)
+        self.eps = torch.empty(shape, **f32)
+        self.time_in = torch.empty(shape[0], 320, **f32)
+        self.noise = torch.empty((max(T - 1, 1),) + tuple(shape), **f32)
+        self.counter = torch.zeros(1, dtype=torch.int32, device=device)
+        # tables in loop order: row s <-> timestep T-1-s
+        self.coef = sched.step_coefficients().flip(0).contiguous().to(device)
+        self.temb = sinusoidal_table(torch.arange(T - 1, -1, -1), 320).contiguous().to(device)
+        self.clip = int(sched.clip_sample)
+        self.stream = torch.cuda.Stream(device)
+        self.kvs = None
+        self.sk = sk
+        self.graph = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self.graph:
+                self.lib.dm_graph_destroy(self.graph)
+        except Exception:
+            pass
+
+    def _body(self):
+        s = self.eng.stream
+        B = self.shape[0]
+        check(self.lib.dm_gather_row(self.temb.data_ptr(), 320, self.counter.data_ptr(), self.time_in.data_ptr(), 320,
+                                     B, 320, s), "gather_row")
+        self.eng.arena.reset()
+        rt.diffusion_forward_into(self.eng, self.pk, self.x, self.time_in, self.kvs, self.sk, self.eps)
+        check(self.lib.dm_ddpm_step(self.x.data_ptr(), self.eps.data_ptr(), self.noise.data_ptr(), self.x.data_ptr(),
+                                    self.x.numel(), self.coef.data_ptr(), self.counter.data_ptr(), self.clip, s),
+              "ddpm_step")
+        check(self.lib.dm_advance_counter(self.counter.data_ptr(), 1, s), "advance_counter")
+
+    def run(self, sched, model, x_T, noises, context, trace):
+        if rt._signature(model) != self.sig:  # parameters changed: repack and drop the stale graph
+            self.eng, self.pk = model.hip_pack(self.device)
+            self.sig = rt._signature(model)
+            if self.graph:
+                self.lib.dm_graph_destroy(self.graph)
+                self.graph = C.c_void_p()
+        caller = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(caller)
+        with torch.cuda.stream(self.stream):
+            self.x.copy_(x_T.to(torch.float32))
+            for i, nz in enumerate(noises):
+                self.noise[i].copy_(nz)
+            self.counter.zero_()
+            self.eng.arena.reset()
+            self.kvs, _ = rt.precompute_context(self.eng, self.pk.unet, context, persistent=self.kvs is None,
+                                                out=self.kvs)
+            done = 0
+            if not self.graph or not sched.use_hip_graph:
+                self._body()  # eager step: packs/arena are warm afterwards
+                done = 1
+                if trace is not None:
+                    trace.append(self.x.clone())
+                if sched.use_hip_graph and self.T > 1:
+                    self.eng.arena.frozen = True
+                    try:
+                        check(self.lib.dm_graph_begin(self.eng.stream), "graph_begin")
+                        self._body()
+                        check(self.lib.dm_graph_end(self.eng.stream, C.byref(self.graph)), "graph_end")
+                    finally:
+                        self.eng.arena.frozen = False
+            for _ in range(done, self.T):
+                if sched.use_hip_graph:
+                    check(self.lib.dm_graph_launch(self.graph, self.eng.stream), "graph_launch")
+                else:
+                    self._body()
+                if trace is not None:
+                    trace.append(self.x.clone())
+            result = self.x.clone()
+        caller.wait_stream(self.stream)
+        return result

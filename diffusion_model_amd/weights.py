@@ -92,3 +92,6 @@ def test_input(name: str, shape: Tuple[int, ...], seed: int = 0, device="cpu",
         numel *= int(s)
     v = unit_uniform("input:" + name, numel, seed, device)
     return (v * (scale * math.sqrt(3.0))).reshape(shape)
+
+
+test_input.__test__ = False  # a data helper, not a pytest case, wherever it gets imported

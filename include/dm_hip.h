@@ -1,0 +1,158 @@
+/* C ABI of libdm_hip.so: hand-written gfx950 (MI355X) kernels for the latent-diffusion
+ * denoising hot path (U-Net noise predictor inside the DDPM sampling loop).
+ *
+ * The reference (sumanthyahoo9/diffusion_model) is pure Python/PyTorch and has no FFI: its
+ * boundary for this path is the call `model(sample, context, time_emb)` made by
+ * DDPMScheduler.sample (src/schedulers/ddpm_scheduler.py:203) plus the torch.nn operators the
+ * model is built from.  Each entry point below therefore cites the reference operator call
+ * site(s) it replaces.  All functions:
+ *   - take raw device pointers, sizes and a hipStream_t; never allocate, free or synchronise
+ *     (so a caller may capture them into a hipGraph); workspaces are passed in by the caller;
+ *   - return 0 (DM_OK) or a positive DM_ERR_* code; nothing is printed;
+ *   - are re-entrant per stream; there is no global state.
+ * Activation matrices are row-major [rows][ld] with channels contiguous (row = (batch, y, x)
+ * or (batch, token)); `dtype` selects fp32 storage/exact-f32 MFMA or bf16 storage/f32 accumulate.
+ */
+#ifndef DM_HIP_H
+#define DM_HIP_H
+
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DM_ABI_VERSION 1
+
+#define DM_F32 0
+#define DM_BF16 1
+
+#define DM_EPI_PLAIN 0    /* C = acc (+bias) (+rowbias[batch]) (+R) */
+#define DM_EPI_GEGLU 1    /* C[m][n] = (acc_v + b_v) * gelu_erf(acc_g + b_g), N counts both halves */
+#define DM_EPI_NCHW_F32 2 /* plain epilogue, stored as fp32 (B, N, H*W) */
+
+#define DM_TILE_AUTO 0
+#define DM_TILE_128x128 1
+#define DM_TILE_64x128 2
+#define DM_TILE_64x64 3
+#define DM_TILE_256x128 4
+#define DM_TILE_32x64 5
+
+int dm_abi_version(void);
+
+/* GEMM / implicit-GEMM conv3x3 with fused epilogue.
+ * Replaces: nn.Linear (src/models/attention.py:19-20,51-54; src/models/blocks.py:109-110),
+ * nn.Conv2d 1x1 (blocks.py:42,99,112), nn.Conv2d 3x3 pad 1 stride 1/2 (blocks.py:33,37;
+ * src/models/unet.py:29,92,97,104,111; src/models/diffusion.py:32), F.interpolate(nearest,x2)
+ * folded into the following conv (unet.py:33-34), the broadcast time add (blocks.py:67), the
+ * residual adds (blocks.py:72,139,145,153,159) and GEGLU (blocks.py:150-151).
+ * `w` is a packed weight matrix made by dm_pack_weight_order() + a gather on the caller side. */
+typedef struct DmGemmDesc {
+    const void* a;        /* activations [m][lda] (conv: NHWC image rows (b, y, x)) */
+    long lda;
+    const void* w;        /* packed weights [npad][kpad], k contiguous */
+    void* c;              /* output [m][ldc] (or fp32 NCHW) */
+    long ldc;
+    const float* bias;    /* [n] fp32 or NULL */
+    const float* rowbias; /* [batch][ld_rowbias] fp32 or NULL; batch = row / rows_per_batch */
+    long ld_rowbias;
+    int rows_per_batch;
+    const void* r;        /* residual [m][ldr], same dtype as c, or NULL */
+    long ldr;
+    int m, n, k;          /* k = 9*cin for conv */
+    int npad, kpad;       /* packed weight extents */
+    int dtype;
+    int conv;             /* 0 dense, 1 conv3x3 pad 1 */
+    int hin, win, hout, wout, cin, stride, up;
+    int epi;
+    int tile;             /* DM_TILE_* (DM_TILE_AUTO: library chooses tile and split) */
+    int splitk;           /* used when tile != AUTO */
+    void* workspace;      /* split-K slabs, >= dm_gemm_workspace_bytes() */
+    long workspace_bytes;
+} DmGemmDesc;
+
+int dm_gemm(const DmGemmDesc* d, hipStream_t stream);
+void dm_gemm_plan(int dtype, int m, int n, int k, int epi, int* tile, int* splitk);
+long dm_gemm_workspace_bytes(int m, int n, int splitk);
+/* order[p] = source weight row of packed row p (or -1 for a zero row), for p in [0, npad). */
+int dm_pack_weight_order(int n, int npad, int geglu, int* order_host);
+
+/* GroupNorm (+ optional SiLU) over NHWC rows.  Replaces nn.GroupNorm(32, C) + F.silu
+ * (blocks.py:58-59,68-69,128; diffusion.py:44-45).  Two launches: per-slab (sum, sumsq)
+ * partials, then normalise.  partial: fp32 [batch][nsplit][groups][2]. */
+int dm_groupnorm_stats(const void* x, long ldx, int batch, int hw, int c, int groups, int dtype,
+                       float* partial, int nsplit, hipStream_t stream);
+int dm_groupnorm_apply(const void* x, long ldx, void* y, long ldy, int batch, int hw, int c, int groups,
+                       int dtype, const float* partial, int nsplit, const float* gamma, const float* beta,
+                       float eps, int silu, hipStream_t stream);
+
+/* LayerNorm over the channel dimension of [rows][c].  Replaces nn.LayerNorm (blocks.py:137,143,149). */
+int dm_layernorm(const void* x, long ldx, void* y, long ldy, int rows, int c, int dtype,
+                 const float* gamma, const float* beta, float eps, hipStream_t stream);
+
+/* softmax(q k^T / sqrt(d)) v for all heads, never materialising the score matrix.
+ * Replaces attention.py:34-43 (self) and attention.py:71-77 (cross).
+ * q rows = (b, sq) at q + (b*sq + s)*ldq + h*d; k likewise with sk; vt is V transposed per head:
+ * vt[((b*heads + h)*d + j)*ldv + key], zero for key in [sk, ldv), ldv a multiple of 64. */
+int dm_attention(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldv, void* o, long ldo,
+                 int batch, int heads, int sq, int sk, int d, int dtype, hipStream_t stream);
+/* src rows (b, s), columns h*d + j  ->  vt as above (pad keys zero-filled). */
+int dm_transpose_v(const void* src, long ld, int batch, int s, int heads, int d, void* vt, long ldv, int dtype,
+                   hipStream_t stream);
+
+/* y[b][n] = sum_k f(x[b][k]) * w[n][k] + bias[n], fp32, f = SiLU when silu_in.  Replaces the
+ * batch-sized Linears of the time path (src/models/embeddings.py:42-44; blocks.py:63-64). */
+int dm_linear_rows(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int batch,
+                   int n, int k, int silu_in, hipStream_t stream);
+
+/* Sinusoidal timestep features, [cos | sin], freqs = exp(-ln(max_period) i / half).
+ * Replaces DDPMScheduler._get_timestep_embedding (ddpm_scheduler.py:212-244). */
+int dm_timestep_embedding(const long long* timesteps, int batch, int dim, float max_period, float* out,
+                          hipStream_t stream);
+
+/* Reverse-process update, fp32, elementwise (ddpm_scheduler.py:99-138):
+ *   x0 = (x - coef[0]*eps)/coef[1]; clamp to [-1,1] if clip; out = coef[2]*x0 + coef[3]*x (+ coef[4]*noise)
+ * coef points at DEVICE memory: 5 floats per step; the row used is coef + 5 * (*step_index) when
+ * step_index != NULL (device int, lets one captured graph serve every step), else coef itself.
+ * noise may be NULL (t == 0); with step_index it is advanced by (*step_index) * n elements. */
+int dm_ddpm_step(const float* x, const float* eps, const float* noise, float* out, long n, const float* coef,
+                 const int* step_index, int clip, hipStream_t stream);
+/* DDIM update (src/schedulers/ddim_scheduler.py:132-164): identical, except that the second term is
+ * coef[3]*eps (the "direction pointing to x_t") instead of coef[3]*x. */
+int dm_ddim_step(const float* x, const float* eps, const float* noise, float* out, long n, const float* coef,
+                 const int* step_index, int clip, hipStream_t stream);
+/* out = a[b]*x + c[b]*y with per-sample scalars gathered from device tables by timestep:
+ * a = ta[t[b]], c = sign*tc[t[b]].  add_noise / get_velocity (base_scheduler.py:145-214). */
+int dm_scale_add(const float* x, const float* y, float* out, int batch, long per_sample, const float* ta,
+                 const float* tc, const long long* t, float sign_c, hipStream_t stream);
+/* out = alpha*x + beta*y (+ gamma*z), fp32 scalars from the host (K-sampler steps, CFG combine). */
+int dm_axpbypcz(const float* x, float alpha, const float* y, float beta, const float* z, float gamma, float* out,
+                long n, hipStream_t stream);
+
+/* Layout / dtype plumbing around the model boundary (fp32 NCHW outside, [rows][C] inside). */
+int dm_nchw_to_rows(const float* src, int batch, int c, int hw, void* dst, long ld, int cpad, int dtype,
+                    hipStream_t stream);
+int dm_rows_to_nchw(const void* src, long ld, int batch, int c, int hw, float* dst, int dtype, hipStream_t stream);
+int dm_convert(const void* src, int src_dtype, void* dst, int dst_dtype, long n, hipStream_t stream);
+/* dst[b][:] = table[*index][:] for b < batch (fp32); *index += step afterwards when advance != 0 is
+ * requested through dm_advance_counter. */
+int dm_gather_row(const float* table, long ld, const int* index, float* dst, long ld_dst, int batch, int n,
+                  hipStream_t stream);
+int dm_advance_counter(int* counter, int delta, hipStream_t stream);
+
+/* hipGraph capture of a sequence of the launches above (the sampler-loop body). */
+int dm_graph_begin(hipStream_t stream);
+int dm_graph_end(hipStream_t stream, void** graph_exec_out);
+int dm_graph_launch(void* graph_exec, hipStream_t stream);
+int dm_graph_destroy(void* graph_exec);
+
+/* Event timing on the caller's stream (used by the benchmark to time kernel classes). */
+int dm_event_create(void** ev);
+int dm_event_record(void* ev, hipStream_t stream);
+int dm_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+int dm_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DM_HIP_H */

@@ -1,0 +1,207 @@
+"""Kernel-level parity: every HIP kernel, called through the C ABI, against fp32 torch math on the CPU.
+
+fp32 mode must agree to rounding (exact-f32 MFMA); bf16 mode is compared against the fp32
+result computed from bf16-rounded inputs with a tolerance stated per test.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import max_rel
+from diffusion_model_amd import _lib
+from diffusion_model_amd.engine import Engine
+from diffusion_model_amd.weights import test_input as tin
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 2e-5
+BF16_TOL = 2e-2
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dt):
+    return F32_TOL if dt == torch.float32 else BF16_TOL
+
+
+def rnd(x, dt):
+    """Round to the engine's storage dtype (what the kernel actually sees) and return fp32."""
+    return x.to(dt).float()
+
+
+def up(eng, x2d):
+    """CPU fp32 [rows, C] -> engine-dtype device rows."""
+    return x2d.to(eng.device).to(eng.dtype).contiguous()
+
+
+@pytest.fixture(params=DTYPES, ids=["f32", "bf16"])
+def eng(request, dev):
+    e = Engine.get(dev, request.param)
+    e.arena.reset()
+    e.tile_override = None
+    return e
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("m,n,k", [(64, 320, 320), (77, 640, 768), (200, 1280, 640), (1024, 320, 1280), (130, 4, 64)])
+@pytest.mark.parametrize("tile", [_lib.TILE_AUTO, _lib.TILE_128x128, _lib.TILE_64x128, _lib.TILE_64x64,
+                                  _lib.TILE_256x128, _lib.TILE_32x64])
+def test_gemm_dense(eng, m, n, k, tile):
+    a = tin("g.a", (m, k)); w = tin("g.w", (n, k), scale=1 / math.sqrt(k)); b = tin("g.b", (n,)); r = tin("g.r", (m, n))
+    lin = torch.nn.Linear(k, n)
+    with torch.no_grad():
+        lin.weight.copy_(w); lin.bias.copy_(b)
+    pw = eng.pack_linear(lin)
+    eng.tile_override = None if tile == _lib.TILE_AUTO else (tile, 1)
+    out = eng.gemm(up(eng, a), pw, residual=up(eng, r))
+    ref = rnd(a, eng.dtype) @ rnd(w, eng.dtype).t() + b + rnd(r, eng.dtype)
+    assert max_rel(out.float(), ref) < tol(eng.dtype)
+
+
+@pytest.mark.parametrize("splitk", [2, 3, 5])
+def test_gemm_splitk_and_strides(eng, splitk):
+    m, n, k = 96, 640, 2560
+    a = tin("s.a", (m, k)); w = tin("s.w", (n, k), scale=1 / math.sqrt(k)); b = tin("s.b", (n,))
+    rb = tin("s.rb", (3, n)); r = tin("s.r", (m, n))
+    lin = torch.nn.Linear(k, n)
+    with torch.no_grad():
+        lin.weight.copy_(w); lin.bias.copy_(b)
+    pw = eng.pack_linear(lin)
+    # strided views: A inside a wider buffer, C and R as channel slices of wider buffers
+    abuf = torch.zeros(m, k + 64, dtype=eng.dtype, device=eng.device); abuf[:, 32:32 + k] = up(eng, a)
+    cbuf = torch.zeros(m, n + 128, dtype=eng.dtype, device=eng.device)
+    rbuf = torch.zeros(m, n + 32, dtype=eng.dtype, device=eng.device); rbuf[:, 32:] = up(eng, r)
+    eng.tile_override = (_lib.TILE_64x64, splitk)
+    eng.gemm(abuf[:, 32:32 + k], pw, out=cbuf[:, 64:64 + n], rowbias=rb.to(eng.device), rows_per_batch=32,
+             residual=rbuf[:, 32:])
+    ref = rnd(a, eng.dtype) @ rnd(w, eng.dtype).t() + b + rb.repeat_interleave(32, 0) + rnd(r, eng.dtype)
+    assert max_rel(cbuf[:, 64:64 + n].float(), ref) < tol(eng.dtype)
+    assert float(cbuf[:, :64].abs().max()) == 0.0 and float(cbuf[:, 64 + n:].abs().max()) == 0.0
+
+
+def test_gemm_geglu(eng):
+    m, c = 150, 320
+    a = tin("gg.a", (m, c)); w = tin("gg.w", (8 * c, c), scale=1 / math.sqrt(c)); b = tin("gg.b", (8 * c,))
+    lin = torch.nn.Linear(c, 8 * c)
+    with torch.no_grad():
+        lin.weight.copy_(w); lin.bias.copy_(b)
+    pw = eng.pack_linear(lin, geglu=True)
+    out = eng.gemm(up(eng, a), pw)
+    y = rnd(a, eng.dtype) @ rnd(w, eng.dtype).t() + b
+    v, g = y.chunk(2, dim=-1)
+    assert out.shape == (m, 4 * c)
+    assert max_rel(out.float(), v * F.gelu(g)) < tol(eng.dtype)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,stride,upx", [(320, 320, 8, 8, 1, 0), (64, 128, 9, 7, 1, 0), (320, 320, 16, 16, 2, 0),
+                                                      (64, 64, 7, 10, 2, 0), (128, 64, 6, 5, 1, 1), (4, 320, 8, 8, 1, 0)])
+def test_conv3x3(eng, cin, cout, h, w, stride, upx):
+    b = 2
+    x = tin("c.x", (b, cin, h, w)); wt = tin("c.w", (cout, cin, 3, 3), scale=1 / math.sqrt(9 * cin)); bias = tin("c.b", (cout,))
+    conv = torch.nn.Conv2d(cin, cout, 3, stride=stride, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(wt); conv.bias.copy_(bias)
+    pw = eng.pack_conv3x3(conv)
+    rows = eng.nchw_to_rows(x.to(eng.device), cpad=pw.conv_cin)
+    xin = rnd(x, eng.dtype)
+    if upx:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, rnd(wt, eng.dtype), bias, stride=stride, padding=1)
+    ho, wo = ref.shape[2], ref.shape[3]
+    out = eng.gemm(rows, pw, conv=dict(batch=b, hin=h, win=w, hout=ho, wout=wo, stride=stride, up=upx, cin_real=cin))
+    got = eng.rows_to_nchw(out, b, cout, ho, wo)
+    assert max_rel(got, ref) < tol(eng.dtype)
+
+
+def test_conv3x3_nchw_epilogue_and_rowbias(eng):
+    b, cin, cout, h, w = 2, 320, 4, 8, 8
+    x = tin("n.x", (b, cin, h, w)); wt = tin("n.w", (cout, cin, 3, 3), scale=0.02); bias = tin("n.b", (cout,))
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(wt); conv.bias.copy_(bias)
+    pw = eng.pack_conv3x3(conv)
+    rows = eng.nchw_to_rows(x.to(eng.device))
+    out = torch.empty(b, cout, h, w, device=eng.device)
+    eng.gemm(rows, pw, nchw_out=out, rows_per_batch=h * w, conv=dict(batch=b, hin=h, win=w, hout=h, wout=w, cin_real=cin))
+    ref = F.conv2d(rnd(x, eng.dtype), rnd(wt, eng.dtype), bias, padding=1)
+    assert max_rel(out, ref) < tol(eng.dtype)
+
+
+def test_gemm_rejects_bad_arguments(eng):
+    lin = torch.nn.Linear(320, 320)
+    pw = eng.pack_linear(lin)
+    with pytest.raises(RuntimeError):
+        eng.gemm(torch.zeros(8, 64, dtype=eng.dtype, device=eng.device), pw)  # K mismatch
+    a = torch.zeros(8, 321, dtype=eng.dtype, device=eng.device)[:, 1:]          # misaligned view
+    with pytest.raises(RuntimeError):
+        eng.gemm(a, pw)
+
+
+# ------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("c,hw,b", [(320, 64, 2), (640, 256, 1), (960, 100, 2), (1920, 64, 1), (2560, 16, 3), (64, 37, 2)])
+@pytest.mark.parametrize("silu", [True, False])
+def test_groupnorm(eng, c, hw, b, silu):
+    x = tin("gn.x", (b, c, hw, 1)) * 2 + 0.5
+    gamma = tin("gn.g", (c,)) + 1; beta = tin("gn.b", (c,))
+    rows = eng.nchw_to_rows(x.to(eng.device))
+    out = eng.groupnorm(rows, b, hw, gamma.to(eng.device), beta.to(eng.device), 1e-6, silu)
+    ref = F.group_norm(rnd(x, eng.dtype), 32, gamma, beta, eps=1e-6)
+    if silu:
+        ref = F.silu(ref)
+    got = eng.rows_to_nchw(out, b, c, hw, 1)
+    assert max_rel(got, ref) < (1e-5 if eng.dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("c,rows", [(320, 130), (640, 64), (1280, 33), (768, 77)])
+def test_layernorm(eng, c, rows):
+    x = tin("ln.x", (rows, c)) * 3 - 1
+    gamma = tin("ln.g", (c,)) + 1; beta = tin("ln.b", (c,))
+    out = eng.layernorm(up(eng, x), gamma.to(eng.device), beta.to(eng.device))
+    ref = F.layer_norm(rnd(x, eng.dtype), (c,), gamma, beta)
+    assert max_rel(out.float(), ref) < (1e-5 if eng.dtype == torch.float32 else 1e-2)
+
+
+# ------------------------------------------------------------------------------------------- attention
+def ref_attention(q, k, v, heads):
+    b, sq, c = q.shape
+    d = c // heads
+    qh, kh, vh = (t.reshape(b, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    w = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(d), dim=-1)
+    return (w @ vh).transpose(1, 2).reshape(b, sq, c)
+
+
+@pytest.mark.parametrize("d,sq,sk", [(40, 256, 256), (40, 64, 77), (80, 100, 100), (80, 256, 77), (160, 64, 64),
+                                     (160, 16, 16), (160, 200, 77), (64, 77, 77)])
+def test_attention(eng, d, sq, sk):
+    b, heads = 2, 8
+    c = heads * d
+    q = tin("at.q", (b, sq, c)); k = tin("at.k", (b, sk, c)); v = tin("at.v", (b, sk, c))
+    # one query row whose scores spike on a late key: forces the online-softmax rescale path
+    k[:, sk - 3] *= 6.0
+    qr, kr, vr = (up(eng, t.reshape(-1, c)) for t in (q, k, v))
+    vt = eng.transpose_v(vr, b, sk, heads, d)
+    out = eng.attention(qr, kr, vt, b, heads, sq, sk, d)
+    ref = ref_attention(rnd(q, eng.dtype), rnd(k, eng.dtype), rnd(v, eng.dtype), heads)
+    assert max_rel(out.float().reshape(b, sq, c), ref) < (2e-5 if eng.dtype == torch.float32 else 2e-2)
+
+
+# ------------------------------------------------------------------------------------------- time path
+def test_linear_rows(dev):
+    eng = Engine.get(dev, torch.float32)
+    eng.arena.reset()
+    for batch in (1, 3, 16):
+        x = tin("lr.x", (batch, 1280)); w = tin("lr.w", (645, 1280), scale=0.03); b = tin("lr.b", (645,))
+        out = eng.linear_rows(x.to(dev), w.to(dev), b.to(dev), silu_in=True)
+        assert max_rel(out, F.linear(F.silu(x), w, b)) < 1e-5
+        out = eng.linear_rows(x.to(dev), w.to(dev), None, silu_in=False)
+        assert max_rel(out, F.linear(x, w)) < 1e-5
+
+
+def test_layout_roundtrip(eng):
+    x = tin("lay.x", (3, 100, 9, 5))
+    rows = eng.nchw_to_rows(x.to(eng.device), cpad=104)
+    assert rows.shape == (3 * 45, 104)
+    assert float(rows[:, 100:].float().abs().max()) == 0.0
+    back = eng.rows_to_nchw(rows, 3, 100, 9, 5)
+    assert torch.equal(back.cpu(), rnd(x, eng.dtype))
