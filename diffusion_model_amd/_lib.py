@@ -14,8 +14,14 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libdm_hip.so")
 DM_F32, DM_BF16 = 0, 1
 EPI_PLAIN, EPI_GEGLU, EPI_NCHW_F32 = 0, 1, 2
 TILE_AUTO, TILE_128x128, TILE_64x128, TILE_64x64, TILE_256x128, TILE_32x64 = 0, 1, 2, 3, 4, 5
+(TILE_D128x128_S2, TILE_D128x128_S3, TILE_D256x128_S3, TILE_D64x128_S3, TILE_D64x128_S4, TILE_D64x64_S4,
+ TILE_D32x64_S4, TILE_D256x64_S3, TILE_D128x64_S4) = range(11, 20)
 TILE_DIMS = {TILE_128x128: (128, 128), TILE_64x128: (64, 128), TILE_64x64: (64, 64),
-             TILE_256x128: (256, 128), TILE_32x64: (32, 64)}
+             TILE_256x128: (256, 128), TILE_32x64: (32, 64),
+             TILE_D128x128_S2: (128, 128), TILE_D128x128_S3: (128, 128), TILE_D256x128_S3: (256, 128),
+             TILE_D64x128_S3: (64, 128), TILE_D64x128_S4: (64, 128), TILE_D64x64_S4: (64, 64),
+             TILE_D32x64_S4: (32, 64), TILE_D256x64_S3: (256, 64), TILE_D128x64_S4: (128, 64)}
+ALL_TILES = tuple(TILE_DIMS)
 
 _ERR = {1: "invalid argument / unsupported shape", 2: "HIP launch error", 3: "misaligned pointer or stride"}
 

@@ -10,9 +10,15 @@
 // consecutive output columns (see pack order below).
 //
 // Block tile BM x BN x (128 bytes of k); 16x16 MFMA fragments; each wave owns a
-// (16*FM) x 64 sub-tile.  Operands go global -> registers -> LDS (XOR-swizzled 128-byte rows,
-// conflict-free ds_read_b128) with the next k-tile's global loads in flight during the
-// current tile's MFMAs; two LDS buffers, one barrier per k-tile.
+// (16*FM) x 64 sub-tile.  LDS tiles are 128-byte rows with an XOR swizzle of the 16-byte chunk
+// index (chunk ^ ((row >> 1) & 7)) that makes the fragment reads (ds_read_b128) conflict-free.
+//
+// Two main loops share the epilogue:
+//   * "direct" (gemm_dma_kernel): operands go global -> LDS with global_load_lds_dwordx4 into a
+//     ring of STAGES tiles; the LDS image is lane-linear, so the swizzle is applied to the per-lane
+//     SOURCE address; padding / out-of-range lanes read a 16-byte zero buffer; counted
+//     s_waitcnt vmcnt(N) + one raw s_barrier per k-tile keep STAGES-1 tiles in flight.
+//   * "staged" (gemm_reg_kernel): global -> registers -> LDS, two LDS buffers, one barrier per k-tile.
 //
 // Packed row order: packed row p = 64*g + 16*j + 4*q + r holds weight row
 //   plain : n = 64*g + 16*q + 4*j + r
@@ -43,192 +49,113 @@ struct GemmArgs {
     float* partial;
 };
 
+// source of every lane whose 16 bytes must read as zero in the direct-to-LDS loop
+__device__ __attribute__((aligned(16))) uint32_t g_zero16[4];
+
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(GemmArgs p) {
-    constexpr int NT = WAVES_M * WAVES_N * 64;
-    constexpr int FM = BM / (16 * WAVES_M);
-    constexpr int FN = 4;
-    static_assert(BN == 64 * WAVES_N, "each wave owns 64 output columns");
-    static_assert(FM >= 1 && BM % (16 * WAVES_M) == 0, "bad tile");
-    constexpr int EPC = ElemTraits<T>::EPC;
-    constexpr int BK = 8 * EPC;  // elements in one 128-byte LDS row
-    constexpr int A_IT = (BM * 8 + NT - 1) / NT;
-    constexpr int W_IT = (BN * 8 + NT - 1) / NT;
-    constexpr int TILE_BYTES = (BM + BN) * 128;
+// XCD-aware tile id: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous run
+// of logical tiles so that neighbours sharing A rows / W columns hit the same L2.  Bijective for any nblk.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// Per-thread coordinates of the A rows it stages (fixed over the k loop).
+template <int A_IT> struct ARows {
+    long off[A_IT];  // dense: element offset of the row; conv: pixel index of image b's origin
+    int y[A_IT], x[A_IT];
+    bool ok[A_IT];
+};
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WAVES_N;
-    const int wn = wave % WAVES_N;
-
-    // ---- tile assignment: give every XCD (blocks b, b+8, ... share one) a contiguous run of
-    // logical tiles so neighbouring tiles that share A rows / W columns hit the same L2.
-    const int ntm = (p.M + BM - 1) / BM;
-    const int ntn = (p.N + BN - 1) / BN;
-    const int nblk = ntm * ntn;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-    }
-    const int tile_m = bid / ntn;
-    const int tile_n = bid - tile_m * ntn;
-    const int m0 = tile_m * BM;
-    const int n0 = tile_n * BN;
-
-    // ---- split-K range
-    const int nkt = p.Kpad / BK;
-    int kt0 = 0, kt1 = nkt;
-    if (p.splitk > 1) {
-        const int per = (nkt + p.splitk - 1) / p.splitk;
-        kt0 = blockIdx.y * per;
-        kt1 = min(nkt, kt0 + per);
-    }
-
-    // ---- per-thread load coordinates (fixed over the k loop)
-    const int chunk = tid & 7;
-    long a_off[A_IT];   // dense: element offset of the row; conv: pixel index of image b's origin
-    int a_y[A_IT], a_x[A_IT];
-    bool a_ok[A_IT];
+template <int A_IT, int ROWS_PER_IT>
+__device__ __forceinline__ void init_rows(ARows<A_IT>& r, const GemmArgs& p, int m0, int row0, int bm) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        const int row = (it * NT + tid) >> 3;
+        const int row = it * ROWS_PER_IT + row0;
         const int m = m0 + row;
-        a_ok[it] = (row < BM) && (m < p.M);
-        a_y[it] = a_x[it] = 0;
-        a_off[it] = 0;
-        if (a_ok[it]) {
+        r.ok[it] = (row < bm) && (m < p.M);
+        r.y[it] = r.x[it] = 0;
+        r.off[it] = 0;
+        if (r.ok[it]) {
             if (p.conv) {
                 const int hw = p.Hout * p.Wout;
                 const int b = m / hw;
                 const int pix = m - b * hw;
-                a_y[it] = pix / p.Wout;
-                a_x[it] = pix - a_y[it] * p.Wout;
-                a_off[it] = (long)b * p.Hin * p.Win;
+                r.y[it] = pix / p.Wout;
+                r.x[it] = pix - r.y[it] * p.Wout;
+                r.off[it] = (long)b * p.Hin * p.Win;
             } else {
-                a_off[it] = (long)m * p.lda;
+                r.off[it] = (long)m * p.lda;
             }
         }
     }
-    const char* w_ptr[W_IT];
-#pragma unroll
-    for (int it = 0; it < W_IT; ++it) {
-        const int row = (it * NT + tid) >> 3;
-        w_ptr[it] = p.W + ((long)(n0 + row) * p.Kpad + chunk * EPC) * sizeof(T);
-    }
-    // conv k-state of this thread's chunk: k = tap * Cin + c
-    int kc = kt0 * BK + chunk * EPC;
-    int tap = 0;
-    if (p.conv) {
-        tap = kc / p.Cin;
-        kc -= tap * p.Cin;
-    }
+}
 
-    u32x4 ra[A_IT], rw[W_IT];
-    auto load_tile = [&](int kt) {
-        if (p.conv) {
-            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+// Element offset (and validity) of the 16-byte piece of A for staged row `it`, conv tap `tap`, channel `kc`.
+template <int A_IT>
+__device__ __forceinline__ bool conv_src(const ARows<A_IT>& r, const GemmArgs& p, int it, int tap, int kc, long& e) {
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    int iy, ix;
+    bool ok = r.ok[it] && tap < 9;
+    if (p.up) {
+        const int uy = r.y[it] + dy, ux = r.x[it] + dx;
+        ok = ok && (unsigned)uy < (unsigned)p.Hout && (unsigned)ux < (unsigned)p.Wout;
+        iy = uy >> 1;
+        ix = ux >> 1;
+    } else {
+        iy = r.y[it] * p.stride + dy;
+        ix = r.x[it] * p.stride + dx;
+        ok = ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+    }
+    e = (r.off[it] + (long)iy * p.Win + ix) * p.lda + kc;
+    return ok;
+}
+
+// One k-tile of MFMAs for this wave from the LDS tile at (sa, sw).
+template <typename T, int FM>
+__device__ __forceinline__ void mma_tile(f32x4 (&acc)[FM][4], const char* sa, const char* sw, int arow0, int wrow0, int fr,
+                                         int fq) {
 #pragma unroll
-            for (int it = 0; it < A_IT; ++it) {
-                int iy, ix;
-                bool ok = a_ok[it] && tap < 9;
-                if (p.up) {
-                    const int uy = a_y[it] + dy, ux = a_x[it] + dx;
-                    ok = ok && (unsigned)uy < (unsigned)p.Hout && (unsigned)ux < (unsigned)p.Wout;
-                    iy = uy >> 1;
-                    ix = ux >> 1;
-                } else {
-                    iy = a_y[it] * p.stride + dy;
-                    ix = a_x[it] * p.stride + dx;
-                    ok = ok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-                }
-                const long e = (a_off[it] + (long)iy * p.Win + ix) * p.lda + kc;
-                ra[it] = ldg16(p.A + e * sizeof(T), ok);
-            }
-            kc += BK;
-            while (kc >= p.Cin) {
-                kc -= p.Cin;
-                ++tap;
-            }
+    for (int ks = 0; ks < 2; ++ks) {
+        u32x4 af[FM], wf[4];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const u32x4*>(sa + swz(arow0 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const u32x4*>(sw + swz(wrow0 + j * 16 + fr, ks * 4 + fq));
+        if constexpr (sizeof(T) == 4) {
+            // 16x16x4 f32 MFMA has a 40-cycle dependent latency against a 32-cycle issue: walk all
+            // accumulators for one k element before touching any of them again
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[j][e]),
+                                                                        __uint_as_float(af[i][e]), acc[i][j], 0, 0, 0);
         } else {
-            const int k = kt * BK + chunk * EPC;
-#pragma unroll
-            for (int it = 0; it < A_IT; ++it)
-                ra[it] = ldg16(p.A + (a_off[it] + k) * sizeof(T), a_ok[it] && k < p.K);
-        }
-#pragma unroll
-        for (int it = 0; it < W_IT; ++it) {
-            const int row = (it * NT + tid) >> 3;
-            rw[it] = ldg16(w_ptr[it] + (long)kt * BK * sizeof(T), row < BN);
-        }
-    };
-    auto store_tile = [&](int buf) {
-        char* sa = smem + buf * TILE_BYTES;
-        char* sw = sa + BM * 128;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int row = (it * NT + tid) >> 3;
-            if (row < BM) *reinterpret_cast<u32x4*>(sa + swz(row, chunk)) = ra[it];
-        }
-#pragma unroll
-        for (int it = 0; it < W_IT; ++it) {
-            const int row = (it * NT + tid) >> 3;
-            if (row < BN) *reinterpret_cast<u32x4*>(sw + swz(row, chunk)) = rw[it];
-        }
-    };
-
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int fr = lane & 15, fq = lane >> 4;
-
-    if (kt0 < kt1) {
-        load_tile(kt0);
-        store_tile(0);
-    }
-    __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        const bool more = kt + 1 < kt1;
-        if (more) load_tile(kt + 1);
-        const char* sa = smem + cur * TILE_BYTES;
-        const char* sw = sa + BM * 128;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            u32x4 af[FM], wf[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-                af[i] = *reinterpret_cast<const u32x4*>(sa + swz(wm * 16 * FM + i * 16 + fr, ks * 4 + fq));
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-                wf[j] = *reinterpret_cast<const u32x4*>(sw + swz(wn * 64 + j * 16 + fr, ks * 4 + fq));
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) Mma16<T>::mma(acc[i][j], wf[j], af[i]);
+                for (int j = 0; j < 4; ++j) Mma16<T>::mma(acc[i][j], wf[j], af[i]);
         }
-        if (more) store_tile(cur ^ 1);
-        __syncthreads();
     }
+}
 
-    // ---- epilogue: lane holds, for row m = .. + fr, columns ncol0 + 4*j + r (16 consecutive)
-    const int ncol0 = n0 + wn * 64 + fq * 16;
+// Epilogue: lane holds, for row m = mrow0 + 16*i + fr, columns ncol0 + 4*j + r (16 consecutive).
+template <typename T, int FM>
+__device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FM][4], int mrow0, int ngroup0, int fr, int fq,
+                                         int kslice) {
+    const int ncol0 = ngroup0 + fq * 16;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm * 16 * FM + i * 16 + fr;
+        const int m = mrow0 + i * 16 + fr;
         if (m >= p.M) continue;
         if (p.splitk > 1) {
-            float* dst = p.partial + ((long)blockIdx.y * p.M + m) * p.N;
+            float* dst = p.partial + ((long)kslice * p.M + m) * p.N;
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
+            for (int j = 0; j < 4; ++j) {
                 const int n = ncol0 + 4 * j;
                 if (n < p.N) *reinterpret_cast<f32x4*>(dst + n) = acc[i][j];
             }
@@ -236,7 +163,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(GemmArgs p)
         }
         if (p.epi == DM_EPI_GEGLU) {
             const int half = p.N >> 1;
-            const int nb = ((n0 + wn * 64) >> 1) + fq * 8;
+            const int nb = (ngroup0 >> 1) + fq * 8;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = nb + 4 * j;
@@ -259,24 +186,35 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(GemmArgs p)
         }
         const int bidx = p.rowbias ? m / p.rows_per_batch : 0;
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
+        for (int j = 0; j < 4; ++j) {
             const int n = ncol0 + 4 * j;
             if (n >= p.N) continue;
             float o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = acc[i][j][r];
             if (p.bias) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] += p.bias[n + r];
+                for (int r = 0; r < 4; ++r) o[r] += b4[r];
             }
             if (p.rowbias) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.rowbias + (long)bidx * p.ld_rowbias + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] += p.rowbias[(long)bidx * p.ld_rowbias + n + r];
+                for (int r = 0; r < 4; ++r) o[r] += b4[r];
             }
             if (p.R) {
                 const T* rp = reinterpret_cast<const T*>(p.R) + (long)m * p.ldr + n;
+                if constexpr (sizeof(T) == 4) {
+                    const f32x4 r4 = *reinterpret_cast<const f32x4*>(rp);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] += ElemTraits<T>::load(rp + r);
+                    for (int r = 0; r < 4; ++r) o[r] += r4[r];
+                } else {
+                    const u32x2 r2 = *reinterpret_cast<const u32x2*>(rp);
+                    o[0] += __uint_as_float(r2[0] << 16);
+                    o[1] += __uint_as_float(r2[0] & 0xffff0000u);
+                    o[2] += __uint_as_float(r2[1] << 16);
+                    o[3] += __uint_as_float(r2[1] & 0xffff0000u);
+                }
             }
             if (p.epi == DM_EPI_NCHW_F32) {
                 const int hw = p.rows_per_batch;
@@ -294,6 +232,260 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(GemmArgs p)
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// direct-to-LDS main loop
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_dma_kernel(GemmArgs p) {
+    constexpr int NT = WAVES_M * WAVES_N * 64;
+    constexpr int FM = BM / (16 * WAVES_M);
+    static_assert(BN == 64 * WAVES_N, "each wave owns 64 output columns");
+    static_assert(BM % (16 * WAVES_M) == 0 && (BM * 8) % NT == 0 && (BN * 8) % NT == 0, "bad tile");
+    static_assert((NT / 8) % 16 == 0, "per-thread swizzle must not depend on the staging iteration");
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int BK = 8 * EPC;
+    constexpr int A_IT = BM * 8 / NT;
+    constexpr int W_IT = BN * 8 / NT;
+    constexpr int LOADS = A_IT + W_IT;           // LDS-DMA instructions per thread per k-tile
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    static_assert((STAGES - 2) * LOADS <= 63, "vmcnt field overflow");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    const int bid = xcd_remap(blockIdx.x, ntm * ntn);
+    const int tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int nkt = p.Kpad / BK;
+    int kt0 = 0, kt1 = nkt;
+    if (p.splitk > 1) {
+        const int per = (nkt + p.splitk - 1) / p.splitk;
+        kt0 = blockIdx.y * per;
+        kt1 = min(nkt, kt0 + per);
+    }
+
+    // This thread always lands on LDS slot (row = it*NT/8 + tid/8, physical chunk tid&7); the logical
+    // chunk stored there is phys ^ ((row>>1)&7) = (tid&7) ^ ((tid>>4)&7), the same for all its rows.
+    const int lchunk = (tid & 7) ^ ((tid >> 4) & 7);
+    ARows<A_IT> rows;
+    init_rows<A_IT, NT / 8>(rows, p, m0, tid >> 3, BM);
+    const char* w_ptr[W_IT];
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it)
+        w_ptr[it] = p.W + ((long)(n0 + it * (NT / 8) + (tid >> 3)) * p.Kpad + lchunk * EPC) * sizeof(T);
+    int kc = kt0 * BK + lchunk * EPC, tap = 0;
+    if (p.conv) {
+        tap = kc / p.Cin;
+        kc -= tap * p.Cin;
+    }
+    const char* zsrc = reinterpret_cast<const char*>(g_zero16);
+    const int lds_wave = wave * 1024;  // wave-uniform part of every destination
+
+    // Fast conv path (Cin a multiple of the k-tile): the tap is the same for every thread of a k-tile
+    // and changes only every Cin/BK tiles, so the per-row source offsets are recomputed only then.
+    const bool conv_fast = p.conv && (p.Cin % BK == 0);
+    long cur[A_IT];
+    bool cur_ok[A_IT];
+    int c0 = 0;  // channel offset of the current k-tile inside its tap
+    if (conv_fast) {
+        c0 = kc - lchunk * EPC;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) cur_ok[it] = conv_src<A_IT>(rows, p, it, tap, lchunk * EPC, cur[it]);
+    }
+
+    auto issue = [&](int kt, int stage) {
+        char* sa = smem + stage * STAGE_BYTES + lds_wave;
+        char* sw = sa + BM * 128;
+        const bool live = kt < kt1;
+        if (conv_fast) {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const char* src = (cur_ok[it] && live) ? p.A + (cur[it] + c0) * sizeof(T) : zsrc;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
+            }
+            c0 += BK;
+            if (c0 == p.Cin) {
+                c0 = 0;
+                ++tap;
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) cur_ok[it] = conv_src<A_IT>(rows, p, it, tap, lchunk * EPC, cur[it]);
+            }
+        } else if (p.conv) {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                long e;
+                const bool ok = conv_src<A_IT>(rows, p, it, tap, kc, e) && live;
+                const char* src = ok ? p.A + e * sizeof(T) : zsrc;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
+            }
+            kc += BK;
+            while (kc >= p.Cin) {
+                kc -= p.Cin;
+                ++tap;
+            }
+        } else {
+            const int k = kt * BK + lchunk * EPC;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const bool ok = rows.ok[it] && k < p.K && live;
+                const char* src = ok ? p.A + (rows.off[it] + k) * sizeof(T) : zsrc;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const char* src = live ? w_ptr[it] + (long)kt * BK * sizeof(T) : zsrc;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sw + it * (NT * 16)), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[FM][4];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // prologue: tiles kt0 .. kt0+STAGES-2 in flight (out-of-range tiles are issued as zero loads so
+    // that every wave's vmcnt arithmetic stays uniform)
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) issue(kt0 + s, s);
+
+    int stage = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        // tile kt has landed once at most (STAGES-2) younger tiles are outstanding; the barrier makes
+        // every wave's share visible and retires all reads of the stage refilled below
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LOADS) : "memory");
+        __builtin_amdgcn_s_barrier();
+        int nstage = stage + STAGES - 1;
+        if (nstage >= STAGES) nstage -= STAGES;
+        issue(kt + STAGES - 1, nstage);
+        const char* sa = smem + stage * STAGE_BYTES;
+        mma_tile<T, FM>(acc, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq);
+        if (++stage == STAGES) stage = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    epilogue<T, FM>(p, acc, m0 + wm * 16 * FM, n0 + wn * 64, fr, fq, blockIdx.y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// register-staged main loop
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_reg_kernel(GemmArgs p) {
+    constexpr int NT = WAVES_M * WAVES_N * 64;
+    constexpr int FM = BM / (16 * WAVES_M);
+    static_assert(BN == 64 * WAVES_N, "each wave owns 64 output columns");
+    static_assert(FM >= 1 && BM % (16 * WAVES_M) == 0, "bad tile");
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int BK = 8 * EPC;
+    constexpr int A_IT = (BM * 8 + NT - 1) / NT;
+    constexpr int W_IT = (BN * 8 + NT - 1) / NT;
+    constexpr int TILE_BYTES = (BM + BN) * 128;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    const int bid = xcd_remap(blockIdx.x, ntm * ntn);
+    const int tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int nkt = p.Kpad / BK;
+    int kt0 = 0, kt1 = nkt;
+    if (p.splitk > 1) {
+        const int per = (nkt + p.splitk - 1) / p.splitk;
+        kt0 = blockIdx.y * per;
+        kt1 = min(nkt, kt0 + per);
+    }
+
+    const int chunk = tid & 7;
+    ARows<A_IT> rows;
+    init_rows<A_IT, NT / 8>(rows, p, m0, tid >> 3, BM);
+    const char* w_ptr[W_IT];
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it)
+        w_ptr[it] = p.W + ((long)(n0 + it * (NT / 8) + (tid >> 3)) * p.Kpad + chunk * EPC) * sizeof(T);
+    int kc = kt0 * BK + chunk * EPC, tap = 0;
+    if (p.conv) {
+        tap = kc / p.Cin;
+        kc -= tap * p.Cin;
+    }
+
+    u32x4 ra[A_IT], rw[W_IT];
+    auto load_tile = [&](int kt) {
+        if (p.conv) {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                long e;
+                const bool ok = conv_src<A_IT>(rows, p, it, tap, kc, e);
+                ra[it] = ldg16(p.A + e * sizeof(T), ok);
+            }
+            kc += BK;
+            while (kc >= p.Cin) {
+                kc -= p.Cin;
+                ++tap;
+            }
+        } else {
+            const int k = kt * BK + chunk * EPC;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it)
+                ra[it] = ldg16(p.A + (rows.off[it] + k) * sizeof(T), rows.ok[it] && k < p.K);
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int row = it * (NT / 8) + (tid >> 3);
+            rw[it] = ldg16(w_ptr[it] + (long)kt * BK * sizeof(T), row < BN);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* sa = smem + buf * TILE_BYTES;
+        char* sw = sa + BM * 128;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int row = it * (NT / 8) + (tid >> 3);
+            if (row < BM) *reinterpret_cast<u32x4*>(sa + swz(row, chunk)) = ra[it];
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int row = it * (NT / 8) + (tid >> 3);
+            if (row < BN) *reinterpret_cast<u32x4*>(sw + swz(row, chunk)) = rw[it];
+        }
+    };
+
+    f32x4 acc[FM][4];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+
+    if (kt0 < kt1) {
+        load_tile(kt0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        const bool more = kt + 1 < kt1;
+        if (more) load_tile(kt + 1);
+        const char* sa = smem + cur * TILE_BYTES;
+        mma_tile<T, FM>(acc, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq);
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    epilogue<T, FM>(p, acc, m0 + wm * 16 * FM, n0 + wn * 64, fr, fq, blockIdx.y);
 }
 
 // Sum split-K partial slabs in slab order (deterministic) and apply the plain epilogue.
@@ -322,79 +514,116 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
     }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
-int launch_cfg(const GemmArgs& a, hipStream_t stream) {
-    constexpr int NT = WAVES_M * WAVES_N * 64;
-    constexpr int LDS = 2 * (BM + BN) * 128;
-    static bool attr_done = false;
-    auto kfn = gemm_kernel<T, BM, BN, WAVES_M, WAVES_N>;
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct TileInfo {
+    int bm, bn, threads, lds;
+};
+
+template <typename K> int launch_kernel(K kfn, bool& attr_done, const TileInfo& t, const GemmArgs& a, hipStream_t stream) {
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, t.lds) !=
             hipSuccess)
             return DM_ERR_LAUNCH;
         attr_done = true;
     }
-    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+    const int ntm = (a.M + t.bm - 1) / t.bm, ntn = (a.N + t.bn - 1) / t.bn;
     dim3 grid(ntm * ntn, a.splitk > 1 ? a.splitk : 1, 1);
-    hipLaunchKernelGGL(kfn, grid, dim3(NT), LDS, stream, a);
+    hipLaunchKernelGGL(kfn, grid, dim3(t.threads), t.lds, stream, a);
     return dm_check_launch();
+}
+
+template <typename T, int BM, int BN, int WM, int WN> int launch_reg(const GemmArgs& a, hipStream_t s) {
+    static bool done = false;
+    const TileInfo t{BM, BN, WM * WN * 64, 2 * (BM + BN) * 128};
+    return launch_kernel(gemm_reg_kernel<T, BM, BN, WM, WN>, done, t, a, s);
+}
+template <typename T, int BM, int BN, int WM, int WN, int ST> int launch_dma(const GemmArgs& a, hipStream_t s) {
+    static bool done = false;
+    const TileInfo t{BM, BN, WM * WN * 64, ST * (BM + BN) * 128};
+    return launch_kernel(gemm_dma_kernel<T, BM, BN, WM, WN, ST>, done, t, a, s);
 }
 
 template <typename T> int launch_typed(const GemmArgs& a, int cfg, hipStream_t s) {
     switch (cfg) {
-        case DM_TILE_128x128: return launch_cfg<T, 128, 128, 2, 2>(a, s);
-        case DM_TILE_64x128: return launch_cfg<T, 64, 128, 2, 2>(a, s);
-        case DM_TILE_64x64: return launch_cfg<T, 64, 64, 4, 1>(a, s);
-        case DM_TILE_256x128: return launch_cfg<T, 256, 128, 4, 2>(a, s);
-        case DM_TILE_32x64: return launch_cfg<T, 32, 64, 2, 1>(a, s);
+        case DM_TILE_128x128: return launch_reg<T, 128, 128, 2, 2>(a, s);
+        case DM_TILE_64x128: return launch_reg<T, 64, 128, 2, 2>(a, s);
+        case DM_TILE_64x64: return launch_reg<T, 64, 64, 4, 1>(a, s);
+        case DM_TILE_256x128: return launch_reg<T, 256, 128, 4, 2>(a, s);
+        case DM_TILE_32x64: return launch_reg<T, 32, 64, 2, 1>(a, s);
+        case DM_TILE_D128x128_S2: return launch_dma<T, 128, 128, 2, 2, 2>(a, s);
+        case DM_TILE_D128x128_S3: return launch_dma<T, 128, 128, 2, 2, 3>(a, s);
+        case DM_TILE_D256x128_S3: return launch_dma<T, 256, 128, 4, 2, 3>(a, s);
+        case DM_TILE_D64x128_S3: return launch_dma<T, 64, 128, 2, 2, 3>(a, s);
+        case DM_TILE_D64x128_S4: return launch_dma<T, 64, 128, 2, 2, 4>(a, s);
+        case DM_TILE_D64x64_S4: return launch_dma<T, 64, 64, 4, 1, 4>(a, s);
+        case DM_TILE_D32x64_S4: return launch_dma<T, 32, 64, 2, 1, 4>(a, s);
+        case DM_TILE_D256x64_S3: return launch_dma<T, 256, 64, 4, 1, 3>(a, s);
+        case DM_TILE_D128x64_S4: return launch_dma<T, 128, 64, 4, 1, 4>(a, s);
         default: return DM_ERR_ARG;
     }
 }
 
 int tile_dims(int cfg, int* bm, int* bn) {
     switch (cfg) {
-        case DM_TILE_128x128: *bm = 128; *bn = 128; return 0;
-        case DM_TILE_64x128: *bm = 64; *bn = 128; return 0;
-        case DM_TILE_64x64: *bm = 64; *bn = 64; return 0;
-        case DM_TILE_256x128: *bm = 256; *bn = 128; return 0;
-        case DM_TILE_32x64: *bm = 32; *bn = 64; return 0;
+        case DM_TILE_128x128: case DM_TILE_D128x128_S2: case DM_TILE_D128x128_S3: *bm = 128; *bn = 128; return 0;
+        case DM_TILE_64x128: case DM_TILE_D64x128_S3: case DM_TILE_D64x128_S4: *bm = 64; *bn = 128; return 0;
+        case DM_TILE_64x64: case DM_TILE_D64x64_S4: *bm = 64; *bn = 64; return 0;
+        case DM_TILE_256x128: case DM_TILE_D256x128_S3: *bm = 256; *bn = 128; return 0;
+        case DM_TILE_32x64: case DM_TILE_D32x64_S4: *bm = 32; *bn = 64; return 0;
+        case DM_TILE_D256x64_S3: *bm = 256; *bn = 64; return 0;
+        case DM_TILE_D128x64_S4: *bm = 128; *bn = 64; return 0;
         default: return 1;
     }
 }
 
 }  // namespace
 
-// Tile / split-K choice when the caller passes tile == DM_TILE_AUTO.  Aim for at least ~2 blocks
-// per CU (256 CUs) with the largest tile that still gets there; below that, split K.
+// Tile / split-K choice when the caller passes tile == DM_TILE_AUTO.
+//
+// Cost model in microseconds.  A CU holds up to `occ` blocks of a tile (LDS-limited); a block alone on
+// a CU runs its MFMAs at the CU rate scaled by the SIMDs it occupies, blocks sharing a CU split the
+// rate; every k-tile iteration also has a latency floor (barrier + LDS round trip).  Split-K adds the
+// slab write/read and one more launch.  Rates are sustained figures measured per tile on MI355X.
 extern "C" void dm_gemm_plan(int dtype, int M, int N, int K, int epi, int* tile, int* splitk) {
-    // Crude cost model (microseconds): blocks are dealt to 256 CUs in rounds; a block's time is
-    // its MFMA work over a per-tile efficiency; split-K adds slab traffic and one more launch.
+    struct Cand { int tile, waves, occ; double cu_tf_bf16, cu_tf_f32; };
+    static const Cand cands[] = {
+        {DM_TILE_D256x128_S3, 8, 1, 3.40, 0.48},
+        {DM_TILE_D128x128_S2, 4, 2, 3.15, 0.48},
+        {DM_TILE_D64x128_S3, 4, 2, 2.40, 0.47},
+        {DM_TILE_D64x64_S4, 4, 2, 1.70, 0.44},
+        {DM_TILE_D32x64_S4, 2, 3, 1.30, 0.42},
+    };
     const int bk = dtype == DM_F32 ? 32 : 64;
     const int nkt = (K + bk - 1) / bk;
-    const int cands[4] = {DM_TILE_128x128, DM_TILE_64x128, DM_TILE_64x64, DM_TILE_32x64};
-    const double eff_bf16[4] = {1.0, 0.8, 0.55, 0.4};
-    const double eff_f32[4] = {1.0, 0.97, 0.92, 0.85};
-    const double cu_flops_per_us = dtype == DM_F32 ? 0.55e6 : 5.0e6;  // sustained per CU
-    const int sks[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+    const double t_lat = 0.30;  // floor per k-tile iteration of one block
+    static const int sks[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
     double best_cost = 1e30;
-    int best = DM_TILE_64x64, best_sk = 1;
-    for (int c = 0; c < 4; ++c) {
+    int best = DM_TILE_D64x64_S4, best_sk = 1;
+    for (const Cand& c : cands) {
+        if (dtype == DM_F32 && c.tile == DM_TILE_D256x128_S3) continue;
         int bm, bn;
-        tile_dims(cands[c], &bm, &bn);
+        tile_dims(c.tile, &bm, &bn);
         const double tiles = (double)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-        const double eff = dtype == DM_F32 ? eff_f32[c] : eff_bf16[c];
-        for (int s = 0; s < 8; ++s) {
-            const int sk = sks[s];
+        const double cu_rate = (dtype == DM_F32 ? c.cu_tf_f32 : c.cu_tf_bf16) * 1e6;  // flop / us
+        const double flops_tile = 2.0 * bm * bn * bk;
+        const double t_alone = flops_tile / (cu_rate * (c.waves >= 4 ? 1.0 : c.waves / 4.0));
+        for (int sk : sks) {
             if (sk > 1 && (epi != DM_EPI_PLAIN || nkt / sk < 4)) break;
             const double blocks = tiles * sk;
-            double rounds = blocks / 256.0;
-            rounds = rounds <= 1.0 ? 1.0 : (double)((long)(rounds * 2.0 + 0.999)) / 2.0;  // half-round steps
-            const double kslice = (double)((nkt + sk - 1) / sk) * bk;
-            double cost = rounds * (2.0 * bm * bn * kslice) / (eff * cu_flops_per_us) + 2.0;
-            if (sk > 1) cost += 2.0 + (double)sk * M * N * 8.0 / 3.0e6;
+            const long per_cu = (long)((blocks + 255.0) / 256.0);
+            const long conc = per_cu < c.occ ? per_cu : c.occ;
+            const long rounds = (per_cu + c.occ - 1) / c.occ;
+            double t_iter = conc * flops_tile / cu_rate;
+            if (t_iter < t_alone) t_iter = t_alone;
+            if (t_iter < t_lat) t_iter = t_lat;
+            const double kslice = (double)((nkt + sk - 1) / sk);
+            double cost = rounds * (kslice + 2.0) * t_iter + 3.0;
+            if (sk > 1) cost += 2.5 + (double)sk * M * N * 8.0 / 4.0e6;
             if (cost < best_cost) {
                 best_cost = cost;
-                best = cands[c];
+                best = c.tile;
                 best_sk = sk;
             }
         }
@@ -435,7 +664,9 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     if (d->n % 4 || d->kpad % bk || d->kpad < d->k) return DM_ERR_ARG;
     if (!dm_aligned16(d->a) || !dm_aligned16(d->w) || (d->lda % epc)) return DM_ERR_ALIGN;
     if (d->epi != DM_EPI_NCHW_F32 && (!dm_aligned16(d->c) || d->ldc % 4)) return DM_ERR_ALIGN;
-    if (d->r && (d->ldr % 4)) return DM_ERR_ALIGN;
+    if (d->r && (d->ldr % 4 || (reinterpret_cast<uintptr_t>(d->r) & 7))) return DM_ERR_ALIGN;
+    if (d->bias && !dm_aligned16(d->bias)) return DM_ERR_ALIGN;
+    if (d->rowbias && (!dm_aligned16(d->rowbias) || d->ld_rowbias % 4)) return DM_ERR_ALIGN;
     if (d->conv) {
         if (d->cin % epc || d->k != 9 * d->cin) return DM_ERR_ARG;
         if (d->stride != 1 && d->stride != 2) return DM_ERR_ARG;

@@ -106,9 +106,9 @@ class Engine:
     def stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 
-    def _prof(self, klass: str, work: float):
+    def _prof(self, klass: str, work: float, tag: str = ""):
         """Context manager timing one launch group with HIP events when profiling is on."""
-        return _Timed(self, klass, work) if self.profile is not None else _NULLCTX
+        return _Timed(self, klass, work, tag) if self.profile is not None else _NULLCTX
 
     def new(self, rows, cols, dtype=None, persistent=False) -> torch.Tensor:
         dtype = dtype or self.dtype
@@ -199,7 +199,9 @@ class Engine:
                     raise RuntimeError("split-K workspace too small during graph capture")
                 self.ws = torch.empty(need * 2, dtype=torch.uint8, device=self.device)
             d.workspace, d.workspace_bytes = self.ws.data_ptr(), self.ws.numel()
-        with self._prof(klass, 2.0 * m * pw.n * (pw.k if conv is None else 9 * conv["cin_real"])):
+        with self._prof(klass, 2.0 * m * pw.n * (pw.k if conv is None else 9 * conv["cin_real"]),
+                        f"m={m} n={pw.n} k={pw.k} tile={tile.value} sk={sk.value} epi={d.epi}"
+                        + (f" s={d.stride} up={d.up}" if conv is not None else "")):
             check(self.lib.dm_gemm(C.byref(d), self.stream), klass)
         return out
 
@@ -210,7 +212,7 @@ class Engine:
             out = self.new(batch * hw, c)
         nsplit = max(1, min(hw // 8, (512 + batch - 1) // batch, 64))
         part = self.arena.alloc(batch * nsplit, groups * 2, torch.float32)
-        with self._prof("groupnorm", float(batch * hw * c * self.esz * 2)):
+        with self._prof("groupnorm", float(batch * hw * c * self.esz * 2), f"b={batch} hw={hw} c={c}"):
             check(self.lib.dm_groupnorm_stats(x.data_ptr(), x.stride(0), batch, hw, c, groups, self.dm,
                                               part.data_ptr(), nsplit, self.stream), "groupnorm_stats")
             check(self.lib.dm_groupnorm_apply(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), batch, hw, c,
@@ -222,7 +224,7 @@ class Engine:
         rows, c = x.shape
         if out is None:
             out = self.new(rows, c)
-        with self._prof("layernorm", float(rows * c * self.esz * 2)):
+        with self._prof("layernorm", float(rows * c * self.esz * 2), f"rows={rows} c={c}"):
             check(self.lib.dm_layernorm(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), rows, c, self.dm,
                                         gamma.data_ptr(), beta.data_ptr(), eps, self.stream), "layernorm")
         return out
@@ -238,7 +240,7 @@ class Engine:
     def attention(self, q, k, vt, batch, heads, sq, sk, d, out=None) -> torch.Tensor:
         if out is None:
             out = self.new(batch * sq, heads * d)
-        with self._prof("attention", 4.0 * batch * heads * sq * sk * d):
+        with self._prof("attention", 4.0 * batch * heads * sq * sk * d, f"b={batch} sq={sq} sk={sk} d={d}"):
             check(self.lib.dm_attention(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), vt.data_ptr(),
                                         vt.stride(0), out.data_ptr(), out.stride(0), batch, heads, sq, sk, d, self.dm,
                                         self.stream), "attention")
@@ -304,19 +306,20 @@ class Engine:
         self.profile = {}
 
     def stop_profile(self) -> Dict[str, dict]:
-        """Synchronise and return {class: {"ms": total, "launches": n, "work": sum}}."""
+        """Synchronise and return {class: {"ms": total, "launches": n, "work": sum, "detail": [(tag, ms, work)]}}."""
         prof, self.profile = self.profile, None
         out = {}
         ms = C.c_float()
         for klass, items in prof.items():
-            tot, work = 0.0, 0.0
-            for e0, e1, w in items:
+            tot, work, detail = 0.0, 0.0, []
+            for e0, e1, w, tag in items:
                 check(self.lib.dm_event_elapsed_ms(e0, e1, C.byref(ms)), "event_elapsed")
                 tot += ms.value
                 work += w
+                detail.append((tag, ms.value, w))
                 self.lib.dm_event_destroy(e0)
                 self.lib.dm_event_destroy(e1)
-            out[klass] = {"ms": tot, "launches": len(items), "work": work}
+            out[klass] = {"ms": tot, "launches": len(items), "work": work, "detail": detail}
         return out
 
 
@@ -332,8 +335,8 @@ _NULLCTX = _Null()
 
 
 class _Timed:
-    def __init__(self, eng: Engine, klass: str, work: float):
-        self.eng, self.klass, self.work = eng, klass, work
+    def __init__(self, eng: Engine, klass: str, work: float, tag: str = ""):
+        self.eng, self.klass, self.work, self.tag = eng, klass, work, tag
 
     def __enter__(self):
         self.e0, self.e1 = C.c_void_p(), C.c_void_p()
@@ -344,5 +347,5 @@ class _Timed:
 
     def __exit__(self, *a):
         check(self.eng.lib.dm_event_record(self.e1, self.eng.stream), "event_record")
-        self.eng.profile.setdefault(self.klass, []).append((self.e0, self.e1, self.work))
+        self.eng.profile.setdefault(self.klass, []).append((self.e0, self.e1, self.work, self.tag))
         return False

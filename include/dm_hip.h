@@ -37,6 +37,16 @@ extern "C" {
 #define DM_TILE_64x64 3
 #define DM_TILE_256x128 4
 #define DM_TILE_32x64 5
+/* direct-to-LDS (global_load_lds) main loop, BMxBN block tile, Sn = LDS ring depth */
+#define DM_TILE_D128x128_S2 11
+#define DM_TILE_D128x128_S3 12
+#define DM_TILE_D256x128_S3 13
+#define DM_TILE_D64x128_S3 14
+#define DM_TILE_D64x128_S4 15
+#define DM_TILE_D64x64_S4 16
+#define DM_TILE_D32x64_S4 17
+#define DM_TILE_D256x64_S3 18
+#define DM_TILE_D128x64_S4 19
 
 int dm_abi_version(void);
 

@@ -45,8 +45,7 @@ def eng(request, dev):
 
 # ------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("m,n,k", [(64, 320, 320), (77, 640, 768), (200, 1280, 640), (1024, 320, 1280), (130, 4, 64)])
-@pytest.mark.parametrize("tile", [_lib.TILE_AUTO, _lib.TILE_128x128, _lib.TILE_64x128, _lib.TILE_64x64,
-                                  _lib.TILE_256x128, _lib.TILE_32x64])
+@pytest.mark.parametrize("tile", (_lib.TILE_AUTO,) + _lib.ALL_TILES)
 def test_gemm_dense(eng, m, n, k, tile):
     a = tin("g.a", (m, k)); w = tin("g.w", (n, k), scale=1 / math.sqrt(k)); b = tin("g.b", (n,)); r = tin("g.r", (m, n))
     lin = torch.nn.Linear(k, n)
@@ -112,6 +111,26 @@ def test_conv3x3(eng, cin, cout, h, w, stride, upx):
     out = eng.gemm(rows, pw, conv=dict(batch=b, hin=h, win=w, hout=ho, wout=wo, stride=stride, up=upx, cin_real=cin))
     got = eng.rows_to_nchw(out, b, cout, ho, wo)
     assert max_rel(got, ref) < tol(eng.dtype)
+
+
+@pytest.mark.parametrize("tile", _lib.ALL_TILES)
+@pytest.mark.parametrize("sk", [1, 3])
+def test_conv3x3_every_tile(eng, tile, sk):
+    b = 2
+    for cin, cout, h, w, stride, upx in ((320, 320, 8, 8, 1, 0), (64, 128, 9, 7, 2, 0), (128, 64, 6, 5, 1, 1), (4, 320, 8, 8, 1, 0)):
+        x = tin("ct.x", (b, cin, h, w)); wt = tin("ct.w", (cout, cin, 3, 3), scale=1 / math.sqrt(9 * cin)); bias = tin("ct.b", (cout,))
+        conv = torch.nn.Conv2d(cin, cout, 3, stride=stride, padding=1)
+        with torch.no_grad():
+            conv.weight.copy_(wt); conv.bias.copy_(bias)
+        pw = eng.pack_conv3x3(conv)
+        rows = eng.nchw_to_rows(x.to(eng.device), cpad=pw.conv_cin)
+        xin = F.interpolate(rnd(x, eng.dtype), scale_factor=2, mode="nearest") if upx else rnd(x, eng.dtype)
+        ref = F.conv2d(xin, rnd(wt, eng.dtype), bias, stride=stride, padding=1)
+        ho, wo = ref.shape[2], ref.shape[3]
+        eng.tile_override = (tile, sk)
+        out = eng.gemm(rows, pw, conv=dict(batch=b, hin=h, win=w, hout=ho, wout=wo, stride=stride, up=upx, cin_real=cin))
+        eng.tile_override = None
+        assert max_rel(eng.rows_to_nchw(out, b, cout, ho, wo), ref) < tol(eng.dtype), (cin, cout, stride, upx)
 
 
 def test_conv3x3_nchw_epilogue_and_rowbias(eng):
