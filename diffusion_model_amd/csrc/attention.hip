@@ -2,14 +2,22 @@
 // ever writing the score matrix.  Non-causal; key count need not be a multiple of the tile.
 //
 // Work split: block = 4 waves = 64*QT query rows of one (batch, head); each wave owns QT tiles of
-// 16 query rows and keeps their Q fragments and the running (max, sum, O) in registers.  K and
-// V^T tiles (128 bytes of keys: 64 bf16 / 32 fp32) are staged through LDS and shared by the 4 waves.
+// 16 query rows and keeps their (pre-scaled) Q fragments and the running (max, sum, O) in registers.
+// K and V^T tiles (128 bytes of keys: 64 bf16 / 32 fp32) are streamed global -> LDS by
+// global_load_lds_dwordx4 into a two-stage ring: tile t+1 is in flight while tile t is consumed,
+// one barrier per tile.  Because that DMA writes LDS lane-linearly, both tile images are
+// contiguous and their bank swizzles are applied to the per-lane SOURCE address:
+//   K   image [k-step][key][64 B], 16-byte chunk c of a row stored at c ^ ((key >> 2) & 3)
+//   V^T image [d][128 B],          16-byte chunk c of a row stored at c ^ ((d >> 1) & 7)
+// Rows / keys outside the problem read a 16-byte zero buffer.
 //
 // The score tile is computed transposed, S^T = K Q^T (K is the MFMA row operand), so that after the
 // MFMA every lane holds scores of ONE query row (column l&15) for keys 4*(l>>4)+r: the row max/sum
 // need only two cross-lane steps, and the probabilities are already laid out as the column
 // operand of the second product O^T = V^T P^T, whose row operand comes from the V^T tile (keys
 // contiguous).  V^T is produced once per projection by dm_transpose_v.
+#include <cstdlib>
+
 #include "common.h"
 #include "dm_hip.h"
 
@@ -24,6 +32,12 @@ struct AttnArgs {
     float scale_log2;  // log2(e) / sqrt(d)
 };
 
+__device__ __attribute__((aligned(16))) uint32_t g_attn_zero16[4];
+
+#define DM_GLDS16(src, dst)                                                                         \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),          \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
 template <typename T, int D, int QT>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     constexpr int EPC = ElemTraits<T>::EPC;
@@ -33,19 +47,69 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     constexpr int DT = (D + 15) / 16;          // 16-row tiles of V^T / O^T
     constexpr int KT = 8 * EPC;                // keys per tile
     constexpr int NKT = KT / 16;
-    constexpr int KROW = NKS * 64 + 16;        // padded LDS row strides (bytes)
-    constexpr int VROW = 128 + 16;
+    constexpr int K_SLAB = KT * 64;            // bytes of one k-step slab
+    constexpr int K_BYTES = NKS * K_SLAB;
+    constexpr int V_BYTES = DT * 16 * 128;
+    constexpr int STAGE = K_BYTES + V_BYTES;
+    constexpr int K_PIECES = K_BYTES / 1024;   // 1 KiB = one wave-instruction of the DMA
+    constexpr int V_PIECES = V_BYTES / 1024;
+    constexpr int KP = (K_PIECES + 3) / 4;     // pieces per wave (upper bound)
+    constexpr int VP = (V_PIECES + 3) / 4;
     static_assert(D % EPC == 0, "head dim must be a whole number of 16-byte chunks");
 
-    __shared__ __attribute__((aligned(16))) char s_k[KT * KROW];
-    __shared__ __attribute__((aligned(16))) char s_v[DT * 16 * VROW];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, qp = lane >> 4;
     const int h = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+    const char* zsrc = reinterpret_cast<const char*>(g_attn_zero16);
 
-    // Q fragments (column operand of S^T): lane supplies Q[row c of tile qt][chunk ks*4+qp]
+    // ---- loader coordinates (fixed over the key loop)
+    long k_off[KP];   // byte offset of this lane's 16 B inside K for tile 0
+    int k_row[KP];    // key row inside the tile (validity against sk), -1 = never valid
+    long v_off[VP];   // byte offset inside V^T for tile 0, -1 = never valid
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        const int pc = wave + 4 * j;
+        const int ks = pc / (KT / 16), row = (pc % (KT / 16)) * 16 + (lane >> 2);
+        const int ch = ks * 4 + ((lane & 3) ^ ((row >> 2) & 3));
+        k_row[j] = (pc < K_PIECES && ch < DCH) ? row : -1;
+        k_off[j] = (((long)b * p.sk + row) * p.ldk + (long)h * D + ch * EPC) * ESZ;
+    }
+#pragma unroll
+    for (int j = 0; j < VP; ++j) {
+        const int pc = wave + 4 * j;
+        const int row = pc * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ ((row >> 1) & 7);
+        v_off[j] = (pc < V_PIECES && row < D) ? ((((long)b * p.heads + h) * D + row) * p.ldv + ch * EPC) * ESZ : -1;
+    }
+    auto issue = [&](int t, int stage) {
+        char* sk_ = smem + stage * STAGE;
+        char* sv_ = sk_ + K_BYTES;
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            const int pc = wave + 4 * j;
+            if (pc < K_PIECES) {  // wave-uniform
+                const bool ok = k_row[j] >= 0 && t * KT + k_row[j] < p.sk;
+                const char* src = ok ? p.k + k_off[j] + (long)t * KT * p.ldk * ESZ : zsrc;
+                DM_GLDS16(src, sk_ + pc * 1024);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VP; ++j) {
+            const int pc = wave + 4 * j;
+            if (pc < V_PIECES) {
+                const char* src = v_off[j] >= 0 ? p.vt + v_off[j] + (long)t * KT * ESZ : zsrc;
+                DM_GLDS16(src, sv_ + pc * 1024);
+            }
+        }
+    };
+
+    const int ntiles = (p.sk + KT - 1) / KT;
+    issue(0, 0);
+
+    // ---- Q fragments (column operand of S^T), pre-multiplied by log2(e)/sqrt(d)
     u32x4 qf[QT][NKS];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -54,7 +118,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         for (int ks = 0; ks < NKS; ++ks) {
             const int ch = ks * 4 + qp;
             const long e = ((long)b * p.sq + row) * p.ldq + (long)h * D + ch * EPC;
-            qf[qt][ks] = ldg16(p.q + e * ESZ, row < p.sq && ch < DCH);
+            const u32x4 raw = ldg16(p.q + e * ESZ, row < p.sq && ch < DCH);
+            float f[EPC];
+            chunk_to_f32<T>(raw, f);
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) f[i] *= p.scale_log2;
+            qf[qt][ks] = f32_to_chunk<T>(f);
         }
     }
 
@@ -70,24 +139,16 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         l_run[qt] = 0.f;
     }
 
-    const int ntiles = (p.sk + KT - 1) / KT;
     for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();
-        // ---- stage K tile [KT][NKS*4 chunks] and V^T tile [DT*16][8 chunks]
-        for (int idx = tid; idx < KT * NKS * 4; idx += 256) {
-            const int row = idx / (NKS * 4), ch = idx - row * (NKS * 4);
-            const int key = t * KT + row;
-            const long e = ((long)b * p.sk + key) * p.ldk + (long)h * D + ch * EPC;
-            *reinterpret_cast<u32x4*>(s_k + row * KROW + ch * 16) = ldg16(p.k + e * ESZ, key < p.sk && ch < DCH);
-        }
-        for (int idx = tid; idx < DT * 16 * 8; idx += 256) {
-            const int row = idx >> 3, ch = idx & 7;
-            const long e = (((long)b * p.heads + h) * D + row) * p.ldv + (long)t * KT + ch * EPC;
-            *reinterpret_cast<u32x4*>(s_v + row * VROW + ch * 16) = ldg16(p.vt + e * ESZ, row < D);
-        }
-        __syncthreads();
+        // tile t has landed (it is the only DMA outstanding); the barrier publishes every wave's share
+        // and retires all reads of the other stage, which is refilled right away
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < ntiles) issue(t + 1, (t + 1) & 1);
+        const char* s_k = smem + (t & 1) * STAGE;
+        const char* s_v = s_k + K_BYTES;
 
-        // ---- S^T = K Q^T
+        // ---- S^T = K Q^T  (already in log2 units)
         f32x4 sacc[NKT][QT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
@@ -97,7 +158,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
-                const u32x4 kf = *reinterpret_cast<const u32x4*>(s_k + (kt * 16 + c) * KROW + (ks * 4 + qp) * 16);
+                const int row = kt * 16 + c;
+                const u32x4 kf =
+                    *reinterpret_cast<const u32x4*>(s_k + ks * K_SLAB + row * 64 + ((qp ^ ((row >> 2) & 3)) << 4));
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) Mma16<T>::mma(sacc[kt][qt], kf, qf[qt][ks]);
             }
@@ -106,16 +169,18 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         const bool tail = (t + 1) * KT > p.sk;
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
+            if (tail) {
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (t * KT + kt * 16 + 4 * qp + r >= p.sk) sacc[kt][qt][r] = -INFINITY;
+            }
             float mloc = -1e30f;
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float s = sacc[kt][qt][r] * p.scale_log2;
-                    if (tail && t * KT + kt * 16 + 4 * qp + r >= p.sk) s = -INFINITY;
-                    sacc[kt][qt][r] = s;
-                    mloc = fmaxf(mloc, s);
-                }
+                for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, sacc[kt][qt][r]);
             mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
             const float mnew = fmaxf(m_run[qt], mloc);
@@ -147,9 +212,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                 }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const char* vp = s_v + (dt * 16 + c) * VROW + kk * 64 + qp * 8;
-                    const u32x2 lo = *reinterpret_cast<const u32x2*>(vp);
-                    const u32x2 hi = *reinterpret_cast<const u32x2*>(vp + 32);
+                    // keys kk*32 + 4*qp .. +3 and +16: bytes kk*64 + 8*qp (+32) of the row
+                    const int row = dt * 16 + c;
+                    const int sw = (row >> 1) & 7;
+                    const char* base = s_v + row * 128 + (qp & 1) * 8;
+                    const int ch = kk * 4 + (qp >> 1);
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(base + ((ch ^ sw) << 4));
+                    const u32x2 hi = *reinterpret_cast<const u32x2*>(base + (((ch + 2) ^ sw) << 4));
                     const u32x4 va = u32x4{lo[0], lo[1], hi[0], hi[1]};
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) Mma16<T>::mma(oacc[dt][qt], va, pb[qt]);
@@ -160,7 +229,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
             for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const u32x4 va = *reinterpret_cast<const u32x4*>(s_v + (dt * 16 + c) * VROW + kt * 64 + qp * 16);
+                    const int row = dt * 16 + c;
+                    const u32x4 va = *reinterpret_cast<const u32x4*>(
+                        s_v + row * 128 + (((kt * 4 + qp) ^ ((row >> 1) & 7)) << 4));
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) {
                         const f32x4 pr = sacc[kt][qt];
@@ -220,15 +291,36 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const T* __restrict__ 
     }
 }
 
-template <typename T, int D> int attn_launch(const AttnArgs& a, int batch, hipStream_t s) {
-    if (a.sq > 64) {
-        dim3 grid((a.sq + 127) / 128, a.heads, batch);
-        hipLaunchKernelGGL((attn_kernel<T, D, 2>), grid, dim3(256), 0, s, a);
-    } else {
-        dim3 grid((a.sq + 63) / 64, a.heads, batch);
-        hipLaunchKernelGGL((attn_kernel<T, D, 1>), grid, dim3(256), 0, s, a);
+template <typename T, int D, int QT> int attn_launch_qt(const AttnArgs& a, int batch, hipStream_t s) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int NKS = (D * (int)sizeof(T) + 63) / 64, DT = (D + 15) / 16, KT = 8 * EPC;
+    constexpr int LDS = 2 * (NKS * KT * 64 + DT * 16 * 128);
+    static bool attr_done = false;
+    auto kfn = attn_kernel<T, D, QT>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+            hipSuccess)
+            return DM_ERR_LAUNCH;
+        attr_done = true;
     }
+    dim3 grid((a.sq + 64 * QT - 1) / (64 * QT), a.heads, batch);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), LDS, s, a);
     return dm_check_launch();
+}
+
+// Rows per block (64*QT): as many as keep >= 2 blocks per CU; wide heads cap QT by registers.
+template <typename T, int D> int attn_launch(const AttnArgs& a, int batch, hipStream_t s) {
+    const long per64 = (long)((a.sq + 63) / 64) * a.heads * batch;
+    static const int forced = getenv("DM_ATTN_QT") ? atoi(getenv("DM_ATTN_QT")) : 0;  // tuning knob
+    if (forced == 1) return attn_launch_qt<T, D, 1>(a, batch, s);
+    if (forced == 2) return attn_launch_qt<T, D, 2>(a, batch, s);
+    if constexpr (D <= 80) {
+        if (forced == 4) return attn_launch_qt<T, D, 4>(a, batch, s);
+    }
+    // Measured on MI355X (bf16 batch 16 and fp32 batch 1, all four U-Net levels): 16 rows per wave wins
+    // everywhere; the extra waves per SIMD hide the softmax VALU work better than wider tiles reuse K.
+    (void)per64;
+    return attn_launch_qt<T, D, 1>(a, batch, s);
 }
 
 template <typename T> int attn_dispatch(const AttnArgs& a, int batch, int d, hipStream_t s) {

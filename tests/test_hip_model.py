@@ -225,3 +225,68 @@ def test_linearity_free_properties_full_size(model_f32, dev):
     one = model_f32(x[1:], ctx[1:], temb[1:])
     assert torch.isfinite(both).all()
     assert max_rel(both[1:], one) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------- K-samplers / CFG
+def test_ksampler_steps_against_reference_goldens(dev):
+    from diffusion_model_amd.sampling import KEulerAncestralSampler, KEulerSampler, KLMSSampler
+    g = load_golden("ksamplers")
+    shape = (1, 4, 8, 8)
+    lat = tin("k.latents", shape).to(dev)
+    outs = [tin(f"k.out{i}", shape).to(dev) for i in range(5)]
+    nz = tin("k.noise", shape).to(dev)
+    ke, cur = KEulerSampler(50), lat
+    for i in range(3):
+        cur = ke.step(cur, outs[i])
+        assert np.array_equal(cur.cpu().numpy(), g[f"k_euler_step{i}"]), i
+    assert ke.step_count == 3
+    ka, cur = KEulerAncestralSampler(50), lat
+    for i in range(3):
+        orig = torch.randn
+        torch.randn = lambda *a, **k: nz.clone()
+        try:
+            cur = ka.step(cur, outs[i])
+        finally:
+            torch.randn = orig
+        assert np.array_equal(cur.cpu().numpy(), g[f"k_ancestral_step{i}"]), i
+    kl, cur = KLMSSampler(50), lat
+    for i in range(5):
+        cur = kl.step(cur, outs[i])
+        assert max_rel(cur, g[f"k_lms_step{i}"]) < 1e-6, i
+    kl.reset()
+    assert kl.outputs == [] and kl.step_count == 0
+
+
+def test_cfg_denoise_loop_matches_oracle(model_f32, dev):
+    """inference.py's K-Euler loop with classifier-free guidance, 3 steps at 16x16, against the CPU oracle."""
+    from diffusion_model_amd import pipeline
+    from diffusion_model_amd.sampling import KEulerSampler
+    state = {k: v.cpu() for k, v in model_f32.state_dict().items()}
+    gen = torch.Generator().manual_seed(11)
+    ctx = torch.randn(2, 77, 768, generator=gen)          # [conditional, unconditional]
+    sampler = KEulerSampler(n_inference_steps=3)
+    lat0 = torch.randn(1, 4, 16, 16, generator=gen) * float(sampler.initial_scale)
+    got = pipeline.denoise(model_f32, sampler, ctx.to(dev), lat0.to(dev), cfg_scale=7.5, do_cfg=True)
+    sig, ts = sched_ref.k_sigmas(3)
+    cur = lat0
+    for i, t in enumerate(ts):
+        temb = sched_ref.timestep_embedding(torch.tensor([int(t)]), 320).repeat(2, 1)
+        inp = (cur * sched_ref.k_input_scale(sig, i)).repeat(2, 1, 1, 1)
+        out = unet_ref.diffusion(state, inp, ctx, temb)
+        c, u = out.chunk(2)
+        cur = sched_ref.k_euler_step(sig, i, cur, 7.5 * (c - u) + u)
+    assert max_rel(got, cur) < 1e-3
+
+
+def test_ddim_sample_matches_oracle(model_f32, dev):
+    T, n = 1000, 2
+    state = {k: v.cpu() for k, v in model_f32.state_dict().items()}
+    ctx = torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(2))
+    d = DDIMScheduler(num_train_timesteps=T, num_inference_steps=n)
+    got = d.sample(model_f32, (1, 4, 16, 16), ctx.to(dev), torch.Generator().manual_seed(9), dev)
+    x = torch.randn((1, 4, 16, 16), generator=torch.Generator().manual_seed(9))
+    tab = sched_ref.make_tables(T)
+    for t in sched_ref.ddim_timesteps(T, n).tolist():
+        eps = unet_ref.diffusion(state, x, ctx, sched_ref.timestep_embedding(torch.tensor([t]), 320))
+        x = sched_ref.ddim_step(tab, eps, t, x, T, n)
+    assert max_rel(got, x) < 1e-3
