@@ -50,6 +50,7 @@ def build_model(device, dtype):
 def kernel_class_profile(model, ctx, latent_hw, batch, device):
     """Eager forward with every launch bracketed by HIP events on the launch stream -> per-class totals."""
     eng, _ = model.hip_pack(device)
+    eng.autotune = True
     x = torch.randn(batch, 4, latent_hw, latent_hw, device=device)
     temb = sinusoidal_table(torch.full((batch,), 25), 320).to(device)
     model(x, ctx, temb)  # warm

@@ -9,6 +9,7 @@ channel slices of the U-Net's skip-concatenation buffers.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -100,6 +101,8 @@ class Engine:
         self.profile: Optional[dict] = None  # kernel class -> [events...] when profiling
         self._order_cache: Dict[Tuple[int, int, bool], torch.Tensor] = {}
         self.tile_override: Optional[Tuple[int, int]] = None
+        self.autotune = os.environ.get("DM_AUTOTUNE", "0") == "1"  # the sampling loop switches it on
+        self.tuned: Dict[tuple, Tuple[int, int]] = {}
 
     # ------------------------------------------------------------------ utilities
     @property
@@ -190,20 +193,69 @@ class Engine:
             if d.epi != _lib.EPI_PLAIN:
                 sk.value = 1
         else:
-            self.lib.dm_gemm_plan(self.dm, m, pw.n, pw.k, d.epi, C.byref(tile), C.byref(sk))
+            key = (m, pw.n, pw.k, d.conv, d.stride, d.up, d.epi, residual is not None, rowbias is not None)
+            best = self.tuned.get(key)
+            if best is None and self.autotune and not self.arena.frozen and self.profile is None:
+                best = self._tune(d, key)
+            if best is not None:
+                tile.value, sk.value = best
+            else:
+                self.lib.dm_gemm_plan(self.dm, m, pw.n, pw.k, d.epi, C.byref(tile), C.byref(sk))
         d.tile, d.splitk = tile.value, sk.value
         if sk.value > 1:
-            need = self.lib.dm_gemm_workspace_bytes(m, pw.n, sk.value)
-            if need > self.ws.numel():
-                if self.arena.frozen:
-                    raise RuntimeError("split-K workspace too small during graph capture")
-                self.ws = torch.empty(need * 2, dtype=torch.uint8, device=self.device)
-            d.workspace, d.workspace_bytes = self.ws.data_ptr(), self.ws.numel()
+            self._bind_workspace(d, m, pw.n, sk.value)
         with self._prof(klass, 2.0 * m * pw.n * (pw.k if conv is None else 9 * conv["cin_real"]),
                         f"m={m} n={pw.n} k={pw.k} tile={tile.value} sk={sk.value} epi={d.epi}"
                         + (f" s={d.stride} up={d.up}" if conv is not None else "")):
             check(self.lib.dm_gemm(C.byref(d), self.stream), klass)
         return out
+
+    def _bind_workspace(self, d: GemmDesc, m: int, n: int, sk: int):
+        need = self.lib.dm_gemm_workspace_bytes(m, n, sk)
+        if need > self.ws.numel():
+            if self.arena.frozen:
+                raise RuntimeError("split-K workspace too small during graph capture")
+            self.ws = torch.empty(need * 2, dtype=torch.uint8, device=self.device)
+        d.workspace, d.workspace_bytes = self.ws.data_ptr(), self.ws.numel()
+
+    # Candidate (tile, split-K) pairs are timed once per distinct problem on the real operands (the
+    # launch is idempotent: it only rewrites the output) and the winner is cached for the process.
+    _TUNE_TILES = (_lib.TILE_D256x128_S3, _lib.TILE_D128x128_S2, _lib.TILE_D64x128_S3, _lib.TILE_D64x64_S4,
+                   _lib.TILE_D32x64_S4)
+    _TUNE_SK = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)
+
+    def _tune(self, d: GemmDesc, key):
+        stream = self.stream
+        nkt = d.kpad // self.bk
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best, best_t = None, float("inf")
+        for tile in self._TUNE_TILES:
+            bm, bn = _lib.TILE_DIMS[tile]
+            if d.npad < _rup(d.n, bn) or (tile == _lib.TILE_D256x128_S3 and d.m < 2048):
+                continue
+            blocks = ((d.m + bm - 1) // bm) * ((d.n + bn - 1) // bn)
+            for sk in self._TUNE_SK:
+                if sk > 1 and (d.epi != _lib.EPI_PLAIN or nkt // sk < 2 or blocks * sk > 8192
+                               or d.m * d.n * sk * 4 > (256 << 20)):
+                    break
+                d.tile, d.splitk = tile, sk
+                if sk > 1:
+                    self._bind_workspace(d, d.m, d.n, sk)
+                if self.lib.dm_gemm(C.byref(d), stream) != 0:
+                    continue
+                e0.record()
+                for _ in range(3):
+                    self.lib.dm_gemm(C.byref(d), stream)
+                e1.record()
+                e1.synchronize()
+                t = e0.elapsed_time(e1)
+                if t < best_t:
+                    best, best_t = (tile, sk), t
+                if blocks * sk >= 2048 and sk > 1:  # already many rounds of blocks; more slices only add slab traffic
+                    break
+        if best is not None:
+            self.tuned[key] = best
+        return best
 
     def groupnorm(self, x: torch.Tensor, batch: int, hw: int, gamma, beta, eps: float, silu: bool,
                   out: Optional[torch.Tensor] = None, groups: int = 32) -> torch.Tensor:

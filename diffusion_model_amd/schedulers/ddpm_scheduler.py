@@ -144,6 +144,7 @@ class _DdpmLoop:
         T = sched.num_train_timesteps
         self.T = T
         self.eng, self.pk = model.hip_pack(device)
+        self.eng.autotune = True  # first (eager) step times tile/split-K candidates per GEMM shape
         self.sig = rt._signature(model)
         f32 = dict(dtype=torch.float32, device=device)
         self.x = torch.empty(shape, **f32)
