@@ -21,6 +21,10 @@ TILE_DIMS = {TILE_128x128: (128, 128), TILE_64x128: (64, 128), TILE_64x64: (64, 
              TILE_D128x128_S2: (128, 128), TILE_D128x128_S3: (128, 128), TILE_D256x128_S3: (256, 128),
              TILE_D64x128_S3: (64, 128), TILE_D64x128_S4: (64, 128), TILE_D64x64_S4: (64, 64),
              TILE_D32x64_S4: (32, 64), TILE_D256x64_S3: (256, 64), TILE_D128x64_S4: (128, 64)}
+TILE_D256x64_S2, TILE_D128x64_S2, TILE_D64x64_S2 = 20, 21, 22
+TILE_D256x256_S2 = 23
+TILE_DIMS.update({TILE_D256x64_S2: (256, 64), TILE_D128x64_S2: (128, 64), TILE_D64x64_S2: (64, 64),
+                  TILE_D256x256_S2: (256, 256)})
 ALL_TILES = tuple(TILE_DIMS)
 
 _ERR = {1: "invalid argument / unsupported shape", 2: "HIP launch error", 3: "misaligned pointer or stride"}

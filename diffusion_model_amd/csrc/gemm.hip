@@ -573,6 +573,10 @@ template <typename T> int launch_typed(const GemmArgs& a, int cfg, hipStream_t s
         case DM_TILE_D32x64_S4: return launch_dma<T, 32, 64, 2, 1, 4>(a, s);
         case DM_TILE_D256x64_S3: return launch_dma<T, 256, 64, 4, 1, 3>(a, s);
         case DM_TILE_D128x64_S4: return launch_dma<T, 128, 64, 4, 1, 4>(a, s);
+        case DM_TILE_D256x64_S2: return launch_dma<T, 256, 64, 4, 1, 2>(a, s);
+        case DM_TILE_D128x64_S2: return launch_dma<T, 128, 64, 4, 1, 2>(a, s);
+        case DM_TILE_D64x64_S2: return launch_dma<T, 64, 64, 4, 1, 2>(a, s);
+        case DM_TILE_D256x256_S2: return launch_dma<T, 256, 256, 2, 4, 2>(a, s);
         default: return DM_ERR_ARG;
     }
 }
@@ -585,7 +589,10 @@ int tile_dims(int cfg, int* bm, int* bn) {
         case DM_TILE_256x128: case DM_TILE_D256x128_S3: *bm = 256; *bn = 128; return 0;
         case DM_TILE_32x64: case DM_TILE_D32x64_S4: *bm = 32; *bn = 64; return 0;
         case DM_TILE_D256x64_S3: *bm = 256; *bn = 64; return 0;
-        case DM_TILE_D128x64_S4: *bm = 128; *bn = 64; return 0;
+        case DM_TILE_D128x64_S4: case DM_TILE_D128x64_S2: *bm = 128; *bn = 64; return 0;
+        case DM_TILE_D256x64_S2: *bm = 256; *bn = 64; return 0;
+        case DM_TILE_D64x64_S2: *bm = 64; *bn = 64; return 0;
+        case DM_TILE_D256x256_S2: *bm = 256; *bn = 256; return 0;
         default: return 1;
     }
 }

@@ -14,7 +14,8 @@ namespace {
 
 constexpr int GN_THREADS = 256;
 constexpr int GN_MAX_SLOTS = 3;   // chunks per thread per row
-constexpr int GN_MAX_C = 5120;    // 3 fp32 LDS tables of C entries in pass 2 stay under 64 KB
+constexpr int GN_UNROLL = 4;      // rows in flight per thread
+constexpr int GN_MAX_C = 4096;    // 3 fp32 LDS tables of C entries + the reduction scratch stay under 64 KB
 
 struct GnGeom {
     int nchunks, slots, tpr, rpi;  // chunks per row, chunk slots per thread, threads per row, rows per iteration
@@ -50,22 +51,31 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
 
     if (active) {
         const T* base = x + ((long)b * hw) * ldx;
-        for (int row = r0 + rl; row < r1; row += g.rpi) {
-            const T* rp = base + (long)row * ldx;
+        // GN_UNROLL rows of loads are issued before any is consumed: a thread streams only 16 bytes
+        // per row, so memory-level parallelism has to come from rows in flight
+        for (int row = r0 + rl; row < r1; row += GN_UNROLL * g.rpi) {
+            u32x4 v[GN_UNROLL][GN_MAX_SLOTS];
 #pragma unroll
-            for (int k = 0; k < GN_MAX_SLOTS; ++k) {
-                const int chunk = lir + k * g.tpr;
-                if (k < g.slots && chunk < g.nchunks) {
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(rp + chunk * EPC);
+            for (int u = 0; u < GN_UNROLL; ++u) {
+                const int rr = row + u * g.rpi;
+#pragma unroll
+                for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+                    const int chunk = lir + k * g.tpr;
+                    v[u][k] = ldg16(base + (long)rr * ldx + chunk * EPC, rr < r1 && k < g.slots && chunk < g.nchunks);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GN_UNROLL; ++u)
+#pragma unroll
+                for (int k = 0; k < GN_MAX_SLOTS; ++k) {
                     float f[EPC];
-                    chunk_to_f32<T>(v, f);
+                    chunk_to_f32<T>(v[u][k], f);  // predicated-off loads are zeros and add nothing
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {
                         s[k][e] += f[e];
                         q[k][e] = fmaf(f[e], f[e], q[k][e]);
                     }
                 }
-            }
         }
     }
     // red[rl][channel][2]
@@ -122,12 +132,26 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
     __shared__ float g_mean[64], g_rstd[64];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int cpg = c / groups;
-    for (int grp = tid; grp < groups; grp += GN_THREADS) {
+    // fold the slab partials: 8 threads per group each sum a strided subset in fp64 (fixed order),
+    // then the group's first thread adds the 8 sub-sums in order
+    __shared__ double sub[64][8][2];
+    for (int item = tid; item < groups * 8; item += GN_THREADS) {
+        const int grp = item >> 3, part = item & 7;
         double a = 0.0, d = 0.0;
-        for (int sp = 0; sp < nsplit; ++sp) {
+        for (int sp = part; sp < nsplit; sp += 8) {
             const float* src = partial + (((long)b * nsplit + sp) * groups + grp) * 2;
             a += (double)src[0];
             d += (double)src[1];
+        }
+        sub[grp][part][0] = a;
+        sub[grp][part][1] = d;
+    }
+    __syncthreads();
+    for (int grp = tid; grp < groups; grp += GN_THREADS) {
+        double a = 0.0, d = 0.0;
+        for (int part = 0; part < 8; ++part) {
+            a += sub[grp][part][0];
+            d += sub[grp][part][1];
         }
         const double n = (double)hw * cpg;
         const double mean = a / n;
@@ -151,21 +175,34 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
     const int r0 = blockIdx.x * rows_per_block, r1 = min(hw, r0 + rows_per_block);
     const T* xb = x + ((long)b * hw) * ldx;
     T* yb = y + ((long)b * hw) * ldy;
-    for (int row = r0 + rl; row < r1; row += g.rpi) {
+    for (int row = r0 + rl; row < r1; row += GN_UNROLL * g.rpi) {
+        u32x4 v[GN_UNROLL][GN_MAX_SLOTS];
 #pragma unroll
-        for (int k = 0; k < GN_MAX_SLOTS; ++k) {
-            const int chunk = lir + k * g.tpr;
-            if (k < g.slots && chunk < g.nchunks) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(xb + (long)row * ldx + chunk * EPC);
-                float f[EPC];
-                chunk_to_f32<T>(v, f);
+        for (int u = 0; u < GN_UNROLL; ++u) {
+            const int rr = row + u * g.rpi;
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                    const int ch = chunk * EPC + e;
-                    float o = (f[e] - t_mean[ch]) * t_scale[ch] + t_beta[ch];
-                    f[e] = silu ? silu_f(o) : o;
+            for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+                const int chunk = lir + k * g.tpr;
+                v[u][k] = ldg16(xb + (long)rr * ldx + chunk * EPC, rr < r1 && k < g.slots && chunk < g.nchunks);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GN_UNROLL; ++u) {
+            const int rr = row + u * g.rpi;
+#pragma unroll
+            for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+                const int chunk = lir + k * g.tpr;
+                if (rr < r1 && k < g.slots && chunk < g.nchunks) {
+                    float f[EPC];
+                    chunk_to_f32<T>(v[u][k], f);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const int ch = chunk * EPC + e;
+                        float o = (f[e] - t_mean[ch]) * t_scale[ch] + t_beta[ch];
+                        f[e] = silu ? silu_f(o) : o;
+                    }
+                    *reinterpret_cast<u32x4*>(yb + (long)rr * ldy + chunk * EPC) = f32_to_chunk<T>(f);
                 }
-                *reinterpret_cast<u32x4*>(yb + (long)row * ldy + chunk * EPC) = f32_to_chunk<T>(f);
             }
         }
     }

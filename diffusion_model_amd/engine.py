@@ -130,7 +130,7 @@ class Engine:
 
     def pack_matrix(self, w2d: torch.Tensor, bias: Optional[torch.Tensor], geglu=False, conv_cin=0) -> PackedWeight:
         n, k = w2d.shape
-        npad, kpad = _rup(n, 128), _rup(k, self.bk)  # widest block tile is 128 columns
+        npad, kpad = _rup(n, 256), _rup(k, self.bk)  # widest block tile is 256 columns
         order = self._order(n, npad, geglu)
         wp = torch.zeros(npad, kpad, dtype=self.dtype, device=self.device)
         valid = order >= 0
@@ -220,8 +220,8 @@ class Engine:
 
     # Candidate (tile, split-K) pairs are timed once per distinct problem on the real operands (the
     # launch is idempotent: it only rewrites the output) and the winner is cached for the process.
-    _TUNE_TILES = (_lib.TILE_D256x128_S3, _lib.TILE_D128x128_S2, _lib.TILE_D64x128_S3, _lib.TILE_D64x64_S4,
-                   _lib.TILE_D32x64_S4)
+    _TUNE_TILES = (_lib.TILE_D256x128_S3, _lib.TILE_D128x128_S2, _lib.TILE_D256x64_S2, _lib.TILE_D128x64_S2,
+                   _lib.TILE_D64x128_S3, _lib.TILE_D64x64_S4, _lib.TILE_D64x64_S2, _lib.TILE_D32x64_S4)
     _TUNE_SK = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)
 
     def _tune(self, d: GemmDesc, key):
@@ -262,7 +262,7 @@ class Engine:
         c = x.shape[1]
         if out is None:
             out = self.new(batch * hw, c)
-        nsplit = max(1, min(hw // 8, (512 + batch - 1) // batch, 64))
+        nsplit = max(1, min(hw // 16, max(32, 2048 // batch), 128))  # slabs of >= 16 rows, ~2k blocks in all
         part = self.arena.alloc(batch * nsplit, groups * 2, torch.float32)
         with self._prof("groupnorm", float(batch * hw * c * self.esz * 2), f"b={batch} hw={hw} c={c}"):
             check(self.lib.dm_groupnorm_stats(x.data_ptr(), x.stride(0), batch, hw, c, groups, self.dm,

@@ -47,6 +47,10 @@ extern "C" {
 #define DM_TILE_D32x64_S4 17
 #define DM_TILE_D256x64_S3 18
 #define DM_TILE_D128x64_S4 19
+#define DM_TILE_D256x64_S2 20
+#define DM_TILE_D128x64_S2 21
+#define DM_TILE_D64x64_S2 22
+#define DM_TILE_D256x256_S2 23 /* 8 waves, each 128x64 */
 
 int dm_abi_version(void);
 
