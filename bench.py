@@ -82,6 +82,19 @@ def cpu_baseline(latent_hw):
                       f"(+1 warm-up): {fwd:.3f} s/forward; images/s extrapolated as 1/(50 x forward)"}
 
 
+def pmc_traffic(config, batch, latent):
+    """HBM bytes per conv3x3 launch from the committed PMC passes of this workload (tools/pmc_traffic.py);
+    None when the run is not one of the profiled configurations."""
+    name = {2: "r01_pmc_traffic_config2_f32.json", 3: "r01_pmc_traffic_config3_bf16.json"}.get(config)
+    if name is None or batch != CONFIGS[config]["batch"] or latent != CONFIGS[config]["latent"]:
+        return None
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return round(json.load(f)["per_launch"].get("conv3x3_igemm_kernel", 0.0)) or None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,9 +174,10 @@ def main():
             "config": {"workload": cfg["name"], "batch_per_gpu": B, "global_batch": B * world,
                        "latent": f"{HW}x{HW}", "ddpm_steps": T, "hip_graph": sched.use_hip_graph,
                        "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel (conv3x3 implicit GEMM)",
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_igemm_kernel",
                          "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(tflops / peak, 4), "traffic": None,
+                         "frac": round(tflops / peak, 4), "traffic": pmc_traffic(args.config, B, HW),
+                         "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, separate passes)",
                          "launches_per_forward": conv["launches"],
                          "avg_launch_us": round(conv["ms"] * 1e3 / conv["launches"], 2)},
             "kernel_classes": classes,

@@ -258,7 +258,10 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
     const int bid = xcd_remap(blockIdx.x, ntm * ntn);
-    const int tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
+    // weight-heavy shapes (N > M) walk M fastest so the blocks sharing a W tile sit in one XCD's L2;
+    // activation-heavy shapes walk N fastest so the A tile is the shared one
+    const int tile_m = p.N > p.M ? bid % ntm : bid / ntn;
+    const int tile_n = p.N > p.M ? bid / ntm : bid - tile_m * ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int nkt = p.Kpad / BK;
@@ -410,7 +413,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_reg_kernel(GemmArg
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
     const int bid = xcd_remap(blockIdx.x, ntm * ntn);
-    const int tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
+    // weight-heavy shapes (N > M) walk M fastest so the blocks sharing a W tile sit in one XCD's L2;
+    // activation-heavy shapes walk N fastest so the A tile is the shared one
+    const int tile_m = p.N > p.M ? bid % ntm : bid / ntn;
+    const int tile_n = p.N > p.M ? bid / ntm : bid - tile_m * ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int nkt = p.Kpad / BK;

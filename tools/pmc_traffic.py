@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch of each kernel class from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE).
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d F -- python3 tools/prof_forward.py --config 2
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d W -- python3 tools/prof_forward.py --config 2
+    python tools/pmc_traffic.py F W profiles/r01_pmc_traffic_config2.json "config 2"
+
+Corrections for gfx950: both counters are in KiB; FETCH_SIZE counts 64 B per 128-B request for wide
+(16 B/lane) coalesced reads, which is what every kernel here issues, so the read side is doubled.
+Only the LAST forward of the run is used (prof_forward runs a warm-up forward first).
+"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+fdir, wdir, out, label = sys.argv[1:5]
+
+
+def load(d, counter):
+    path = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return rows
+
+
+def klass(name):
+    m = re.search(r"(conv3x3_igemm_kernel|gemm_dma_kernel|attn_kernel|gn_stats_kernel|gn_apply_kernel|layernorm_kernel|"
+                  r"splitk_reduce_kernel|transpose_v_kernel|linear_rows_kernel)", name)
+    return m.group(1) if m else None
+
+
+def last_forward(rows):
+    """Dispatches of the final forward: everything after the last nchw_to_rows launch (first kernel of a forward's U-Net)."""
+    idx = max(i for i, r in enumerate(rows) if "linear_rows_kernel" in r["Kernel_Name"])
+    # a forward starts with 3 linear_rows launches; step back to the first of that run
+    while idx > 0 and "linear_rows_kernel" in rows[idx - 1]["Kernel_Name"]:
+        idx -= 1
+    return rows[idx:]
+
+
+res = collections.defaultdict(lambda: {"launches": 0, "fetch_bytes": 0.0, "write_bytes": 0.0})
+for r in last_forward(load(fdir, "FETCH_SIZE")):
+    k = klass(r["Kernel_Name"])
+    if k:
+        res[k]["launches"] += 1
+        res[k]["fetch_bytes"] += float(r["Counter_Value"]) * 1024 * 2
+for r in last_forward(load(wdir, "WRITE_SIZE")):
+    k = klass(r["Kernel_Name"])
+    if k:
+        res[k]["write_bytes"] += float(r["Counter_Value"]) * 1024
+summary = {"label": label, "unit": "bytes", "corrections": "KiB->bytes; FETCH_SIZE x2 (gfx950 halves wide coalesced reads)",
+           "per_forward": {}, "per_launch": {}}
+for k, v in res.items():
+    tot = v["fetch_bytes"] + v["write_bytes"]
+    summary["per_forward"][k] = {"launches": v["launches"], "fetch": v["fetch_bytes"], "write": v["write_bytes"], "total": tot}
+    summary["per_launch"][k] = tot / max(v["launches"], 1)
+json.dump(summary, open(out, "w"), indent=1)
+for k, v in sorted(summary["per_forward"].items(), key=lambda kv: -kv[1]["total"]):
+    print(f"{k:24s} x{v['launches']:3d}  fetch {v['fetch']/1e6:9.1f} MB  write {v['write']/1e6:9.1f} MB  per launch {summary['per_launch'][k]/1e6:8.2f} MB")
