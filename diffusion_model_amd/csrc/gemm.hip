@@ -260,8 +260,9 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
     const int bid = xcd_remap(blockIdx.x, ntm * ntn);
     // weight-heavy shapes (N > M) walk M fastest so the blocks sharing a W tile sit in one XCD's L2;
     // activation-heavy shapes walk N fastest so the A tile is the shared one
-    const int tile_m = p.N > p.M ? bid % ntm : bid / ntn;
-    const int tile_n = p.N > p.M ? bid / ntm : bid - tile_m * ntn;
+    const bool m_fast = (p.conv ? 9 * p.N : p.N) > p.M;  // unique W bytes vs unique A bytes
+    const int tile_m = m_fast ? bid % ntm : bid / ntn;
+    const int tile_n = m_fast ? bid / ntm : bid - tile_m * ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int nkt = p.Kpad / BK;
@@ -415,8 +416,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_reg_kernel(GemmArg
     const int bid = xcd_remap(blockIdx.x, ntm * ntn);
     // weight-heavy shapes (N > M) walk M fastest so the blocks sharing a W tile sit in one XCD's L2;
     // activation-heavy shapes walk N fastest so the A tile is the shared one
-    const int tile_m = p.N > p.M ? bid % ntm : bid / ntn;
-    const int tile_n = p.N > p.M ? bid / ntm : bid - tile_m * ntn;
+    const bool m_fast = (p.conv ? 9 * p.N : p.N) > p.M;  // unique W bytes vs unique A bytes
+    const int tile_m = m_fast ? bid % ntm : bid / ntn;
+    const int tile_n = m_fast ? bid / ntm : bid - tile_m * ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int nkt = p.Kpad / BK;
