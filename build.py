@@ -29,7 +29,10 @@ def _stale(target, deps):
 
 # The scheduler-step kernels promise separately rounded fp32 operations (bitwise equal to fp32
 # torch); hipcc's default would contract a*b+c into an FMA.
-EXTRA = {"elementwise.hip": ["-ffp-contract=off"]}
+# Attention reads its score accumulators with VALU every tile: keep MFMA results in VGPRs instead of
+# AGPRs (saves a v_accvgpr_read/write per value).
+EXTRA = {"elementwise.hip": ["-ffp-contract=off"],
+         "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _compile(src):

@@ -7,15 +7,23 @@
 // global_load_lds_dwordx4 into a two-stage ring: tile t+1 is in flight while tile t is consumed,
 // one barrier per tile.  Because that DMA writes LDS lane-linearly, both tile images are
 // contiguous and their bank swizzles are applied to the per-lane SOURCE address:
-//   K   image [k-step][key][64 B], 16-byte chunk c of a row stored at c ^ ((key >> 2) & 3)
+//   K   image [k-step][key][64 B], 16-byte chunk c of a row stored at c ^ ksw(key)
 //   V^T image [d][128 B],          16-byte chunk c of a row stored at c ^ ((d >> 1) & 7)
 // Rows / keys outside the problem read a 16-byte zero buffer.
+// A 128-bit LDS read is served in four cycles, and the lanes sharing a cycle are NOT 16 consecutive
+// ones: measured on MI355X they are {0-3, 12-15, 20-23, 24-27}, {4-7, 8-11, 16-19, 28-31} and the same
+// two sets + 32.  With lane = 16*chunk + row, ksw() is chosen so that those sets hit 16 distinct
+// 16-byte slots of the 256-byte bank line: (key >> 1) & 3 for fp32 (rows = consecutive keys) and
+// (-(key >> 3)) & 3 for the permuted bf16 rows described below.
 //
 // The score tile is computed transposed, S^T = K Q^T (K is the MFMA row operand), so that after the
 // MFMA every lane holds scores of ONE query row (column l&15) for keys 4*(l>>4)+r: the row max/sum
 // need only two cross-lane steps, and the probabilities are already laid out as the column
 // operand of the second product O^T = V^T P^T, whose row operand comes from the V^T tile (keys
 // contiguous).  V^T is produced once per projection by dm_transpose_v.
+// For bf16 the 16 rows of score block kt are NOT keys 16*kt..16*kt+15: row 4*q + r of block kt is key
+// 32*(kt>>1) + 8*q + 4*(kt&1) + r, so that a lane's results from blocks 2j and 2j+1 are 8 consecutive
+// keys, i.e. exactly one 16-byte chunk of a V^T row (one ds_read_b128 per MFMA operand).
 #include <cstdlib>
 
 #include "common.h"
@@ -29,10 +37,14 @@ struct AttnArgs {
     const char* vt; long ldv;
     char* o; long ldo;
     int heads, sq, sk;
+    int nqblk, nblk;   // query blocks per (batch, head); blocks in the grid
     float scale_log2;  // log2(e) / sqrt(d)
 };
 
 __device__ __attribute__((aligned(16))) uint32_t g_attn_zero16[4];
+// 16 bytes of 1.0 (bf16 / fp32): source of the extra V^T row whose product with P^T is the row sum
+__device__ __attribute__((aligned(16))) uint32_t g_attn_ones_bf16[4] = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+__device__ __attribute__((aligned(16))) uint32_t g_attn_ones_f32[4] = {0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u};
 
 #define DM_GLDS16(src, dst)                                                                         \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),          \
@@ -55,25 +67,39 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     constexpr int V_PIECES = V_BYTES / 1024;
     constexpr int KP = (K_PIECES + 3) / 4;     // pieces per wave (upper bound)
     constexpr int VP = (V_PIECES + 3) / 4;
+    // When D leaves spare rows in the last 16-row tile of V^T, row D is fed with ones so that the
+    // second product also delivers sum_k P[q][k] (in O^T row D) and the VALU never adds the row sum.
+    constexpr bool ONES = (D % 16) != 0;
+    auto ksw = [](int row) { return ESZ == 2 ? (-(row >> 3)) & 3 : (row >> 1) & 3; };
     static_assert(D % EPC == 0, "head dim must be a whole number of 16-byte chunks");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, qp = lane >> 4;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+    // Blocks i, i+8, ... run on one XCD (one L2).  Hand each XCD a contiguous run of (batch, head,
+    // query block) ids, query block fastest, so that every block streaming one head's K / V^T sits behind
+    // the same L2 at about the same time and those tiles are fetched from HBM once.
+    int logical;
+    {
+        const int bid = blockIdx.x, nq8 = p.nblk >> 3, r8 = p.nblk & 7, x = bid & 7;
+        logical = (x < r8 ? x * (nq8 + 1) : r8 * (nq8 + 1) + (x - r8) * nq8) + (bid >> 3);
+    }
+    const int bh = logical / p.nqblk;
+    const int h = bh % p.heads, b = bh / p.heads;
+    const int q0 = (logical - bh * p.nqblk) * (64 * QT) + wave * (16 * QT);
     const char* zsrc = reinterpret_cast<const char*>(g_attn_zero16);
 
     // ---- loader coordinates (fixed over the key loop)
     long k_off[KP];   // byte offset of this lane's 16 B inside K for tile 0
     int k_row[KP];    // key row inside the tile (validity against sk), -1 = never valid
-    long v_off[VP];   // byte offset inside V^T for tile 0, -1 = never valid
+    const char* v_src[VP];  // this lane's 16 B of V^T for tile 0 (or the constant zero / ones buffer)
+    int v_adv[VP];          // bytes to advance per tile (0 for the constant buffers)
 #pragma unroll
     for (int j = 0; j < KP; ++j) {
         const int pc = wave + 4 * j;
         const int ks = pc / (KT / 16), row = (pc % (KT / 16)) * 16 + (lane >> 2);
-        const int ch = ks * 4 + ((lane & 3) ^ ((row >> 2) & 3));
+        const int ch = ks * 4 + ((lane & 3) ^ ksw(row));
         k_row[j] = (pc < K_PIECES && ch < DCH) ? row : -1;
         k_off[j] = (((long)b * p.sk + row) * p.ldk + (long)h * D + ch * EPC) * ESZ;
     }
@@ -82,7 +108,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         const int pc = wave + 4 * j;
         const int row = pc * 8 + (lane >> 3);
         const int ch = (lane & 7) ^ ((row >> 1) & 7);
-        v_off[j] = (pc < V_PIECES && row < D) ? ((((long)b * p.heads + h) * D + row) * p.ldv + ch * EPC) * ESZ : -1;
+        v_src[j] = zsrc;
+        v_adv[j] = 0;
+        if (pc < V_PIECES && row < D) {
+            v_src[j] = p.vt + ((((long)b * p.heads + h) * D + row) * p.ldv + ch * EPC) * ESZ;
+            v_adv[j] = KT * ESZ;
+        } else if (ONES && row == D) {
+            v_src[j] = reinterpret_cast<const char*>(ESZ == 2 ? g_attn_ones_bf16 : g_attn_ones_f32);
+        }
     }
     auto issue = [&](int t, int stage) {
         char* sk_ = smem + stage * STAGE;
@@ -100,10 +133,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         for (int j = 0; j < VP; ++j) {
             const int pc = wave + 4 * j;
             if (pc < V_PIECES) {
-                const char* src = v_off[j] >= 0 ? p.vt + v_off[j] + (long)t * KT * ESZ : zsrc;
-                DM_GLDS16(src, sv_ + pc * 1024);
+                DM_GLDS16(v_src[j] + (long)t * v_adv[j], sv_ + pc * 1024);
             }
         }
+    };
+
+    // key (inside the tile) that row i of score block kt stands for
+    auto key_of = [](int kt, int i) {
+        return ESZ == 2 ? 32 * (kt >> 1) + 8 * (i >> 2) + 4 * (kt & 1) + (i & 3) : 16 * kt + i;
     };
 
     const int ntiles = (p.sk + KT - 1) / KT;
@@ -132,10 +169,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) oacc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run[QT], l_run[QT];
+    // Scores are kept relative to a per-row REFERENCE m_ref that only moves when a tile's maximum
+    // exceeds it by more than 2^8: the MFMA chain starts from -m_ref, so S^T arrives already shifted and
+    // the common path is just exp2 + convert.  Any reference gives the same softmax after the final
+    // division; staying within 2^8 of the true maximum keeps exp2 far from overflow.
+    float m_ref[QT], l_run[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        m_run[qt] = -1e30f;
+        m_ref[qt] = 0.f;
         l_run[qt] = 0.f;
     }
 
@@ -148,24 +189,30 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         const char* s_k = smem + (t & 1) * STAGE;
         const char* s_v = s_k + K_BYTES;
 
-        // ---- S^T = K Q^T  (already in log2 units)
+        // ---- S^T - m_ref = K Q^T - m_ref  (log2 units); K fragments are fetched one k-step ahead
         f32x4 sacc[NKT][QT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) sacc[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
+            for (int qt = 0; qt < QT; ++qt) sacc[kt][qt] = f32x4{-m_ref[qt], -m_ref[qt], -m_ref[qt], -m_ref[qt]};
+        u32x4 kf[2][NKT];
+        auto load_k = [&](int ks, u32x4 (&dst)[NKT]) {
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
-                const int row = kt * 16 + c;
-                const u32x4 kf =
-                    *reinterpret_cast<const u32x4*>(s_k + ks * K_SLAB + row * 64 + ((qp ^ ((row >> 2) & 3)) << 4));
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) Mma16<T>::mma(sacc[kt][qt], kf, qf[qt][ks]);
+                const int row = key_of(kt, c);
+                dst[kt] = *reinterpret_cast<const u32x4*>(s_k + ks * K_SLAB + row * 64 + ((qp ^ ksw(row)) << 4));
             }
+        };
+        load_k(0, kf[0]);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks + 1 < NKS) load_k(ks + 1, kf[(ks + 1) & 1]);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) Mma16<T>::mma(sacc[kt][qt], kf[ks & 1][kt], qf[qt][ks]);
         }
-        // ---- online softmax; lane holds keys t*KT + kt*16 + 4*qp + r of query row c
+        // ---- softmax numerators; lane holds keys t*KT + key_of(kt, 4*qp + r) of query row c
         const bool tail = (t + 1) * KT > p.sk;
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
@@ -174,30 +221,39 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                 for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (t * KT + kt * 16 + 4 * qp + r >= p.sk) sacc[kt][qt][r] = -INFINITY;
+                        if (t * KT + key_of(kt, 4 * qp + r) >= p.sk) sacc[kt][qt][r] = -INFINITY;
             }
-            float mloc = -1e30f;
+            float mloc = sacc[0][qt][0];
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, sacc[kt][qt][r]);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-            const float mnew = fmaxf(m_run[qt], mloc);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - mnew);
-            m_run[qt] = mnew;
+            // wave-uniform: the first tile fixes the reference exactly, later ones only when some row
+            // outgrew it by 2^8
+            if (t == 0 || __builtin_amdgcn_ballot_w64(mloc > 8.f) != 0) {
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+                const float delta = t == 0 ? mloc : fmaxf(mloc, 0.f);
+                m_ref[qt] += delta;
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc[kt][qt][r] -= delta;
+                l_run[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) oacc[dt][qt] *= alpha;
+            }
             float psum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(sacc[kt][qt][r] - mnew);
+                    const float pv = __builtin_amdgcn_exp2f(sacc[kt][qt][r]);
                     sacc[kt][qt][r] = pv;
-                    psum += pv;
+                    if constexpr (!ONES) psum += pv;
                 }
-            l_run[qt] = l_run[qt] * alpha + psum;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) oacc[dt][qt] *= alpha;
+            if constexpr (!ONES) l_run[qt] += psum;
         }
         // ---- O^T += V^T P^T
         if constexpr (sizeof(T) == 2) {
@@ -212,14 +268,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                 }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    // keys kk*32 + 4*qp .. +3 and +16: bytes kk*64 + 8*qp (+32) of the row
+                    // keys kk*32 + 8*qp .. +7: chunk kk*4 + qp of the row
                     const int row = dt * 16 + c;
-                    const int sw = (row >> 1) & 7;
-                    const char* base = s_v + row * 128 + (qp & 1) * 8;
-                    const int ch = kk * 4 + (qp >> 1);
-                    const u32x2 lo = *reinterpret_cast<const u32x2*>(base + ((ch ^ sw) << 4));
-                    const u32x2 hi = *reinterpret_cast<const u32x2*>(base + (((ch + 2) ^ sw) << 4));
-                    const u32x4 va = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                    const u32x4 va = *reinterpret_cast<const u32x4*>(
+                        s_v + row * 128 + (((kk * 4 + qp) ^ ((row >> 1) & 7)) << 4));
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) Mma16<T>::mma(oacc[dt][qt], va, pb[qt]);
                 }
@@ -247,9 +299,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     // ---- normalise and store: lane holds O[row c][d = dt*16 + 4*qp + r]
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        float l = l_run[qt];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        float l;
+        if constexpr (ONES) {
+            // O^T row D (the ones row) sits in tile DT-1 at lane group (D % 16) / 4, element D % 4
+            l = __shfl(oacc[DT - 1][qt][D % 4], ((D % 16) / 4) * 16 + c);
+        } else {
+            l = l_run[qt];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+        }
         const float inv = 1.0f / l;
         const int row = q0 + qt * 16 + c;
         if (row >= p.sq) continue;
@@ -303,8 +361,12 @@ template <typename T, int D, int QT> int attn_launch_qt(const AttnArgs& a, int b
             return DM_ERR_LAUNCH;
         attr_done = true;
     }
-    dim3 grid((a.sq + 64 * QT - 1) / (64 * QT), a.heads, batch);
-    hipLaunchKernelGGL(kfn, grid, dim3(256), LDS, s, a);
+    AttnArgs args = a;
+    args.nqblk = (a.sq + 64 * QT - 1) / (64 * QT);
+    const long nblk = (long)args.nqblk * a.heads * batch;
+    if (nblk > 0x7fffffffL) return DM_ERR_ARG;
+    args.nblk = (int)nblk;
+    hipLaunchKernelGGL(kfn, dim3(args.nblk), dim3(256), LDS, s, args);
     return dm_check_launch();
 }
 

@@ -34,7 +34,10 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return __builtin_bit_cast(bf16_t, h);
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    // one v_cvt_pk_bf16_f32 for the pair (a scalar conversion per half costs two plus an OR)
+    typedef float dm_f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 dm_bf16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(dm_f32x2{lo, hi}, dm_bf16x2));
 }
 
 template <typename T> struct ElemTraits;
