@@ -106,6 +106,20 @@ template <> struct Mma16<float> {
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// GELU(erf) for outputs that are rounded to bf16: erf by Abramowitz-Stegun 7.1.26 (|error| < 2e-7,
+// far below half a bf16 ulp), one rcp + one exp2 + six FMAs instead of the branchy libm erff.
+__device__ __forceinline__ float gelu_erf_fast_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    const float erf_abs = fmaf(-poly * t, e, 1.0f);  // erf(|x| / sqrt 2)
+    return 0.5f * x + 0.5f * fabsf(x) * erf_abs;     // 0.5 x (1 + sign(x) erf_abs)
+}
+
 // 16-byte global load with a zero default (predicated-off lanes read nothing).
 __device__ __forceinline__ u32x4 ldg16(const void* p, bool pred) {
     u32x4 z = {0u, 0u, 0u, 0u};

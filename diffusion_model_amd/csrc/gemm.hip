@@ -144,76 +144,116 @@ __device__ __forceinline__ void mma_tile(f32x4 (&acc)[FM][4], const char* sa, co
 }
 
 // Epilogue: lane holds, for row m = mrow0 + 16*i + fr, columns ncol0 + 4*j + r (16 consecutive).
+// Column-only terms (bias) are fetched once per lane, outside the row loop; bf16 rows are written as
+// 16-byte pieces.
 template <typename T, int FM>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FM][4], int mrow0, int ngroup0, int fr, int fq,
                                          int kslice) {
     const int ncol0 = ngroup0 + fq * 16;
+    if (p.splitk > 1) {
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int m = mrow0 + i * 16 + fr;
-        if (m >= p.M) continue;
-        if (p.splitk > 1) {
+        for (int i = 0; i < FM; ++i) {
+            const int m = mrow0 + i * 16 + fr;
+            if (m >= p.M) continue;
             float* dst = p.partial + ((long)kslice * p.M + m) * p.N;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = ncol0 + 4 * j;
                 if (n < p.N) *reinterpret_cast<f32x4*>(dst + n) = acc[i][j];
             }
-            continue;
         }
-        if (p.epi == DM_EPI_GEGLU) {
-            const int half = p.N >> 1;
-            const int nb = (ngroup0 >> 1) + fq * 8;
+        return;
+    }
+    if (p.epi == DM_EPI_GEGLU) {
+        // lane holds 8 value columns nb..nb+7 (j = 0, 1) and their gates (j = 2, 3)
+        const int half = p.N >> 1;
+        const int nb = (ngroup0 >> 1) + fq * 8;
+        if (nb >= half) return;  // N/2 is a multiple of 8 (checked on the host)
+        f32x4 bv[2], bg[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = nb + 4 * j;
-                if (n >= half) continue;
-                float o[4];
+        for (int j = 0; j < 2; ++j) {
+            bv[j] = *reinterpret_cast<const f32x4*>(p.bias + nb + 4 * j);
+            bg[j] = *reinterpret_cast<const f32x4*>(p.bias + half + nb + 4 * j);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = mrow0 + i * 16 + fr;
+            if (m >= p.M) continue;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = acc[i][j][r] + p.bias[n + r];
-                    const float g = acc[i][j + 2][r] + p.bias[half + n + r];
-                    o[r] = v * gelu_erf_f(g);
+                    const float v = acc[i][j][r] + bv[j][r];
+                    const float g = acc[i][j + 2][r] + bg[j][r];
+                    if constexpr (sizeof(T) == 4) o[4 * j + r] = v * gelu_erf_f(g);
+                    else o[4 * j + r] = v * gelu_erf_fast_f(g);
                 }
-                T* dst = reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n;
-                if constexpr (sizeof(T) == 4) {
-                    *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
-                } else {
-                    *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-                }
+            T* dst = reinterpret_cast<T*>(p.C) + (long)m * p.ldc + nb;
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
+            } else {
+                *reinterpret_cast<u32x4*>(dst) = u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]),
+                                                       pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
             }
-            continue;
         }
+        return;
+    }
+    f32x4 b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        b4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias && ncol0 + 4 * j < p.N) b4[j] = *reinterpret_cast<const f32x4*>(p.bias + ncol0 + 4 * j);
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = mrow0 + i * 16 + fr;
+        if (m >= p.M) continue;
         const int bidx = p.rowbias ? m / p.rows_per_batch : 0;
+        // two 8-column halves; N is a multiple of 4, so a half is all-valid, half-valid or absent
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = ncol0 + 4 * j;
+        for (int h = 0; h < 2; ++h) {
+            const int n = ncol0 + 8 * h;
             if (n >= p.N) continue;
-            float o[4];
+            const bool full = n + 8 <= p.N;
+            float o[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = acc[i][j][r];
-            if (p.bias) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] += b4[r];
-            }
+            for (int q = 0; q < 8; ++q) o[q] = acc[i][2 * h + (q >> 2)][q & 3] + b4[2 * h + (q >> 2)][q & 3];
             if (p.rowbias) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.rowbias + (long)bidx * p.ld_rowbias + n);
+                const float* rb = p.rowbias + (long)bidx * p.ld_rowbias + n;
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(rb);
+                const f32x4 r1 = full ? *reinterpret_cast<const f32x4*>(rb + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] += b4[r];
+                for (int r = 0; r < 4; ++r) {
+                    o[r] += r0[r];
+                    o[4 + r] += r1[r];
+                }
             }
             if (p.R) {
                 const T* rp = reinterpret_cast<const T*>(p.R) + (long)m * p.ldr + n;
                 if constexpr (sizeof(T) == 4) {
-                    const f32x4 r4 = *reinterpret_cast<const f32x4*>(rp);
+                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp);
+                    const f32x4 r1 = full ? *reinterpret_cast<const f32x4*>(rp + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] += r4[r];
+                    for (int r = 0; r < 4; ++r) {
+                        o[r] += r0[r];
+                        o[4 + r] += r1[r];
+                    }
                 } else {
-                    const u32x2 r2 = *reinterpret_cast<const u32x2*>(rp);
-                    o[0] += __uint_as_float(r2[0] << 16);
-                    o[1] += __uint_as_float(r2[0] & 0xffff0000u);
-                    o[2] += __uint_as_float(r2[1] << 16);
-                    o[3] += __uint_as_float(r2[1] & 0xffff0000u);
+                    u32x4 rr = {0u, 0u, 0u, 0u};
+                    if (full) {
+                        rr = *reinterpret_cast<const u32x4*>(rp);
+                    } else {
+                        const u32x2 r2 = *reinterpret_cast<const u32x2*>(rp);
+                        rr[0] = r2[0];
+                        rr[1] = r2[1];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        o[2 * q] += __uint_as_float(rr[q] << 16);
+                        o[2 * q + 1] += __uint_as_float(rr[q] & 0xffff0000u);
+                    }
                 }
             }
             if (p.epi == DM_EPI_NCHW_F32) {
@@ -221,11 +261,16 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FM][4],
                 const int b = m / hw, pix = m - b * hw;
                 float* dst = reinterpret_cast<float*>(p.C);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[((long)b * p.N + n + r) * hw + pix] = o[r];
+                for (int q = 0; q < 8; ++q)
+                    if (q < 4 || full) dst[((long)b * p.N + n + q) * hw + pix] = o[q];
             } else {
                 T* dst = reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n;
                 if constexpr (sizeof(T) == 4) {
                     *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+                    if (full) *reinterpret_cast<f32x4*>(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
+                } else if (full) {
+                    *reinterpret_cast<u32x4*>(dst) = u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]),
+                                                           pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
                 } else {
                     *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
                 }
@@ -690,8 +735,9 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     const int epc = 16 / esz, bk = 8 * epc;
     if (d->n % 4 || d->kpad % bk || d->kpad < d->k) return DM_ERR_ARG;
     if (!dm_aligned16(d->a) || !dm_aligned16(d->w) || (d->lda % epc)) return DM_ERR_ALIGN;
-    if (d->epi != DM_EPI_NCHW_F32 && (!dm_aligned16(d->c) || d->ldc % 4)) return DM_ERR_ALIGN;
-    if (d->r && (d->ldr % 4 || (reinterpret_cast<uintptr_t>(d->r) & 7))) return DM_ERR_ALIGN;
+    // output / residual rows are accessed as 16-byte pieces
+    if (d->epi != DM_EPI_NCHW_F32 && (!dm_aligned16(d->c) || d->ldc % epc)) return DM_ERR_ALIGN;
+    if (d->r && (d->ldr % epc || !dm_aligned16(d->r))) return DM_ERR_ALIGN;
     if (d->bias && !dm_aligned16(d->bias)) return DM_ERR_ALIGN;
     if (d->rowbias && (!dm_aligned16(d->rowbias) || d->ld_rowbias % 4)) return DM_ERR_ALIGN;
     if (d->conv) {

@@ -65,7 +65,7 @@ typedef struct DmGemmDesc {
     const void* a;        /* activations [m][lda] (conv: NHWC image rows (b, y, x)) */
     long lda;
     const void* w;        /* packed weights [npad][kpad], k contiguous */
-    void* c;              /* output [m][ldc] (or fp32 NCHW) */
+    void* c;              /* output [m][ldc] (or fp32 NCHW); c, r 16-byte aligned, ldc, ldr multiples of 16 bytes */
     long ldc;
     const float* bias;    /* [n] fp32 or NULL */
     const float* rowbias; /* [batch][ld_rowbias] fp32 or NULL; batch = row / rows_per_batch */

@@ -53,9 +53,14 @@ def test_gemm_dense(eng, m, n, k, tile):
         lin.weight.copy_(w); lin.bias.copy_(b)
     pw = eng.pack_linear(lin)
     eng.tile_override = None if tile == _lib.TILE_AUTO else (tile, 1)
-    out = eng.gemm(up(eng, a), pw, residual=up(eng, r))
+    # rows of C and R are accessed as 16-byte pieces: n = 4 lives in buffers with a leading dimension of 8
+    ld = (n + 7) // 8 * 8
+    cbuf = torch.zeros(m, ld, dtype=eng.dtype, device=eng.device)
+    rbuf = torch.zeros(m, ld, dtype=eng.dtype, device=eng.device); rbuf[:, :n] = up(eng, r)
+    out = eng.gemm(up(eng, a), pw, out=cbuf[:, :n], residual=rbuf[:, :n])
     ref = rnd(a, eng.dtype) @ rnd(w, eng.dtype).t() + b + rnd(r, eng.dtype)
     assert max_rel(out.float(), ref) < tol(eng.dtype)
+    assert float(cbuf[:, n:].abs().max() if ld > n else 0.0) == 0.0
 
 
 @pytest.mark.parametrize("splitk", [2, 3, 5])
