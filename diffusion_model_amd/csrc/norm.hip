@@ -7,6 +7,8 @@
 // order (bitwise reproducible).  Pass 2 folds the slab partials, then normalises + affine
 // (+ SiLU) with the same coalesced sweep.  The second read of x is served by the 256 MiB
 // Infinity Cache for every tensor on this path.
+#include <cstdlib>
+
 #include "common.h"
 #include "dm_hip.h"
 
@@ -15,7 +17,7 @@ namespace {
 constexpr int GN_THREADS = 256;
 constexpr int GN_MAX_SLOTS = 3;   // chunks per thread per row
 constexpr int GN_UNROLL = 4;      // rows in flight per thread
-constexpr int GN_MAX_C = 4096;    // 3 fp32 LDS tables of C entries + the reduction scratch stay under 64 KB
+constexpr int GN_MAX_C = 4096;    // 2 fp32 LDS tables of C entries + the reduction scratch stay under 64 KB
 
 struct GnGeom {
     int nchunks, slots, tpr, rpi;  // chunks per row, chunk slots per thread, threads per row, rows per iteration
@@ -34,7 +36,7 @@ template <typename T>
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restrict__ x, long ldx, int hw, int c,
                                                                int groups, float* __restrict__ partial, int nsplit) {
     constexpr int EPC = ElemTraits<T>::EPC;
-    __shared__ float red[GN_THREADS * GN_MAX_SLOTS * EPC * 2];
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [rows per iteration][c][2]
     const GnGeom g = gn_geom<T>(c);
     const int split = blockIdx.x, b = blockIdx.y;
     const int rows_per = (hw + nsplit - 1) / nsplit;
@@ -125,10 +127,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
                                                                const float* __restrict__ beta, float eps, int silu,
                                                                int rows_per_block) {
     constexpr int EPC = ElemTraits<T>::EPC;
-    extern __shared__ __attribute__((aligned(16))) float tab[];  // mean[c] | scale[c] | beta[c]
-    float* t_mean = tab;
-    float* t_scale = tab + c;
-    float* t_beta = tab + 2 * c;
+    extern __shared__ __attribute__((aligned(16))) float tab[];  // scale[c] | shift[c]: y = x*scale + shift
+    float* t_scale = tab;
+    float* t_shift = tab + c;
     __shared__ float g_mean[64], g_rstd[64];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int cpg = c / groups;
@@ -163,15 +164,27 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
     __syncthreads();
     for (int ch = tid; ch < c; ch += GN_THREADS) {
         const int grp = ch / cpg;
-        t_mean[ch] = g_mean[grp];
-        t_scale[ch] = g_rstd[grp] * gamma[ch];
-        t_beta[ch] = beta[ch];
+        const float sc = g_rstd[grp] * gamma[ch];
+        t_scale[ch] = sc;
+        t_shift[ch] = fmaf(-g_mean[grp], sc, beta[ch]);
     }
     __syncthreads();
 
     const GnGeom g = gn_geom<T>(c);
     const int lir = tid % g.tpr, rl = tid / g.tpr;
     if (rl >= g.rpi) return;
+    // a thread owns the same channel chunks on every row: keep their scale / shift in registers
+    float sc[GN_MAX_SLOTS][EPC], sh[GN_MAX_SLOTS][EPC];
+#pragma unroll
+    for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+        const int chunk = lir + k * g.tpr;
+        const bool ok = k < g.slots && chunk < g.nchunks;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            sc[k][e] = ok ? t_scale[chunk * EPC + e] : 0.f;
+            sh[k][e] = ok ? t_shift[chunk * EPC + e] : 0.f;
+        }
+    }
     const int r0 = blockIdx.x * rows_per_block, r1 = min(hw, r0 + rows_per_block);
     const T* xb = x + ((long)b * hw) * ldx;
     T* yb = y + ((long)b * hw) * ldy;
@@ -197,9 +210,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
                     chunk_to_f32<T>(v[u][k], f);
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {
-                        const int ch = chunk * EPC + e;
-                        float o = (f[e] - t_mean[ch]) * t_scale[ch] + t_beta[ch];
-                        f[e] = silu ? silu_f(o) : o;
+                        const float o = fmaf(f[e], sc[k][e], sh[k][e]);
+                        if constexpr (sizeof(T) == 4) {
+                            f[e] = silu ? silu_f(o) : o;
+                        } else {
+                            // bf16 output: reciprocal instead of the IEEE division sequence
+                            f[e] = silu ? o * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * o)) : o;
+                        }
                     }
                     *reinterpret_cast<u32x4*>(yb + (long)rr * ldy + chunk * EPC) = f32_to_chunk<T>(f);
                 }
@@ -270,8 +287,8 @@ template <typename T> int gn_stats_launch(const void* x, long ldx, int batch, in
                                           int nsplit, hipStream_t s) {
     const GnGeom g = gn_geom<T>(c);
     if (g.slots > GN_MAX_SLOTS) return DM_ERR_ARG;
-    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(nsplit, batch), dim3(GN_THREADS), 0, s, static_cast<const T*>(x), ldx, hw,
-                       c, groups, partial, nsplit);
+    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(nsplit, batch), dim3(GN_THREADS), (size_t)g.rpi * c * 2 * sizeof(float),
+                       s, static_cast<const T*>(x), ldx, hw, c, groups, partial, nsplit);
     return dm_check_launch();
 }
 
@@ -282,11 +299,12 @@ int gn_apply_launch(const void* x, long ldx, void* y, long ldy, int batch, int h
     const GnGeom g = gn_geom<T>(c);
     if (g.slots > GN_MAX_SLOTS || c > GN_MAX_C) return DM_ERR_ARG;
     // enough blocks to fill the chip, at least rpi rows each
-    int want = (2048 + batch - 1) / batch;
+    static const int total_blocks = getenv("DM_GN_APPLY_BLOCKS") ? atoi(getenv("DM_GN_APPLY_BLOCKS")) : 1024;  // tuning knob
+    int want = (total_blocks + batch - 1) / batch;
     int rows_per_block = (hw + want - 1) / want;
     if (rows_per_block < g.rpi) rows_per_block = g.rpi;
     const int nb = (hw + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(nb, batch), dim3(GN_THREADS), 3 * c * sizeof(float), s,
+    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(nb, batch), dim3(GN_THREADS), 2 * c * sizeof(float), s,
                        static_cast<const T*>(x), ldx, static_cast<T*>(y), ldy, hw, c, groups, partial, nsplit, gamma,
                        beta, eps, silu, rows_per_block);
     return dm_check_launch();

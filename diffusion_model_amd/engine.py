@@ -102,6 +102,7 @@ class Engine:
         self._order_cache: Dict[Tuple[int, int, bool], torch.Tensor] = {}
         self.tile_override: Optional[Tuple[int, int]] = None
         self.autotune = os.environ.get("DM_AUTOTUNE", "0") == "1"  # the sampling loop switches it on
+        self.gn_blocks = int(os.environ.get("DM_GN_BLOCKS", "1024"))  # GroupNorm statistics blocks per launch
         self.tuned: Dict[tuple, Tuple[int, int]] = {}
 
     # ------------------------------------------------------------------ utilities
@@ -262,7 +263,7 @@ class Engine:
         c = x.shape[1]
         if out is None:
             out = self.new(batch * hw, c)
-        nsplit = max(1, min(hw // 16, max(32, 2048 // batch), 128))  # slabs of >= 16 rows, ~2k blocks in all
+        nsplit = max(1, min(hw // 16, max(8, self.gn_blocks // batch), 128))  # slabs of >= 16 rows
         part = self.arena.alloc(batch * nsplit, groups * 2, torch.float32)
         with self._prof("groupnorm", float(batch * hw * c * self.esz * 2), f"b={batch} hw={hw} c={c}"):
             check(self.lib.dm_groupnorm_stats(x.data_ptr(), x.stride(0), batch, hw, c, groups, self.dm,
