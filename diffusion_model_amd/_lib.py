@@ -57,6 +57,7 @@ _PROTOS = {
     "dm_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "dm_gemm_plan": (None, [_i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "dm_gemm_workspace_bytes": (C.c_long, [_i, _i, _i]),
+    "dm_gemm_streamk_workspace_bytes": (C.c_long, [_i, _i, _i, _i]),
     "dm_pack_weight_order": (C.c_int, [_i, _i, _i, _vp]),
     "dm_groupnorm_stats": (C.c_int, [_vp, _l, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "dm_groupnorm_apply": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp]),

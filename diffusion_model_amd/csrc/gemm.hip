@@ -47,6 +47,9 @@ struct GemmArgs {
     int epi;
     int splitk;
     float* partial;
+    int streamk;    // stream-K: number of blocks sharing the (tile, k-tile) work list; 0 = one tile per block
+    int* counters;  // stream-K: one arrival counter per output tile, zero on entry, left zero
+    float* slabs;   // stream-K: 2 accumulator slabs per block
 };
 
 // source of every lane whose 16 bytes must read as zero in the direct-to-LDS loop
@@ -302,129 +305,201 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-    const int bid = xcd_remap(blockIdx.x, ntm * ntn);
+    const int nkt = p.Kpad / BK;
+    const int fr = lane & 15, fq = lane >> 4;
     // weight-heavy shapes (N > M) walk M fastest so the blocks sharing a W tile sit in one XCD's L2;
     // activation-heavy shapes walk N fastest so the A tile is the shared one
     const bool m_fast = (p.conv ? 9 * p.N : p.N) > p.M;  // unique W bytes vs unique A bytes
-    const int tile_m = m_fast ? bid % ntm : bid / ntn;
-    const int tile_n = m_fast ? bid / ntm : bid - tile_m * ntn;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    const int nkt = p.Kpad / BK;
-    int kt0 = 0, kt1 = nkt;
-    if (p.splitk > 1) {
-        const int per = (nkt + p.splitk - 1) / p.splitk;
-        kt0 = blockIdx.y * per;
-        kt1 = min(nkt, kt0 + per);
-    }
-
+    const char* zsrc = reinterpret_cast<const char*>(g_zero16);
+    const int lds_wave = wave * 1024;  // wave-uniform part of every destination
     // This thread always lands on LDS slot (row = it*NT/8 + tid/8, physical chunk tid&7); the logical
     // chunk stored there is phys ^ ((row>>1)&7) = (tid&7) ^ ((tid>>4)&7), the same for all its rows.
     const int lchunk = (tid & 7) ^ ((tid >> 4) & 7);
-    ARows<A_IT> rows;
-    init_rows<A_IT, NT / 8>(rows, p, m0, tid >> 3, BM);
-    const char* w_ptr[W_IT];
-#pragma unroll
-    for (int it = 0; it < W_IT; ++it)
-        w_ptr[it] = p.W + ((long)(n0 + it * (NT / 8) + (tid >> 3)) * p.Kpad + lchunk * EPC) * sizeof(T);
-    int kc = kt0 * BK + lchunk * EPC, tap = 0;
-    if (CONV) {
-        tap = kc / p.Cin;
-        kc -= tap * p.Cin;
-    }
-    const char* zsrc = reinterpret_cast<const char*>(g_zero16);
-    const int lds_wave = wave * 1024;  // wave-uniform part of every destination
 
-    // Fast conv path (Cin a multiple of the k-tile): the tap is the same for every thread of a k-tile
-    // and changes only every Cin/BK tiles, so the per-row source offsets are recomputed only then.
-    const bool conv_fast = CONV && (p.Cin % BK == 0);
-    long cur[A_IT];
-    bool cur_ok[A_IT];
-    int c0 = 0;  // channel offset of the current k-tile inside its tap
-    if (conv_fast) {
-        c0 = kc - lchunk * EPC;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) cur_ok[it] = conv_src<A_IT>(rows, p, it, tap, lchunk * EPC, cur[it]);
+    // Work list.  One tile per block: tile = blockIdx.x, k range = slice blockIdx.y of splitk.
+    // Stream-K: the (tile, k-tile) pairs, tile-major, are cut into gridDim.x equal runs; a block walks
+    // its run segment by segment (at most one tile entered late and one left early).
+    long u = 0, u_end = 1;
+    int sk_g = 0;
+    if (p.streamk) {
+        sk_g = xcd_remap(blockIdx.x, gridDim.x);
+        const long U = (long)ntm * ntn * nkt;
+        u = sk_g * U / gridDim.x;
+        u_end = (sk_g + 1) * U / gridDim.x;
     }
 
-    auto issue = [&](int kt, int stage) {
-        char* sa = smem + stage * STAGE_BYTES + lds_wave;
-        char* sw = sa + BM * 128;
-        const bool live = kt < kt1;
-        if (conv_fast) {
-#pragma unroll
-            for (int it = 0; it < A_IT; ++it) {
-                const char* src = (cur_ok[it] && live) ? p.A + (cur[it] + c0) * sizeof(T) : zsrc;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
-            }
-            c0 += BK;
-            if (c0 == p.Cin) {
-                c0 = 0;
-                ++tap;
-#pragma unroll
-                for (int it = 0; it < A_IT; ++it) cur_ok[it] = conv_src<A_IT>(rows, p, it, tap, lchunk * EPC, cur[it]);
-            }
-        } else if (CONV) {
-#pragma unroll
-            for (int it = 0; it < A_IT; ++it) {
-                long e;
-                const bool ok = conv_src<A_IT>(rows, p, it, tap, kc, e) && live;
-                const char* src = ok ? p.A + e * sizeof(T) : zsrc;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
-            }
-            kc += BK;
-            while (kc >= p.Cin) {
-                kc -= p.Cin;
-                ++tap;
-            }
+    while (u < u_end) {
+        int tile_id, kt0, kt1;
+        if (p.streamk) {
+            tile_id = (int)(u / nkt);
+            kt0 = (int)(u - (long)tile_id * nkt);
+            kt1 = (int)min((long)nkt, kt0 + (u_end - u));
+            u += kt1 - kt0;
+            // the previous segment's LDS reads (and ticket word) are done before the ring is refilled
+            __syncthreads();
         } else {
-            const int k = kt * BK + lchunk * EPC;
+            tile_id = xcd_remap(blockIdx.x, ntm * ntn);
+            kt0 = 0;
+            kt1 = nkt;
+            if (p.splitk > 1) {
+                const int per = (nkt + p.splitk - 1) / p.splitk;
+                kt0 = blockIdx.y * per;
+                kt1 = min(nkt, kt0 + per);
+            }
+            u = u_end;
+        }
+        const int tile_m = m_fast ? tile_id % ntm : tile_id / ntn;
+        const int tile_n = m_fast ? tile_id / ntm : tile_id - tile_m * ntn;
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+        ARows<A_IT> rows;
+        init_rows<A_IT, NT / 8>(rows, p, m0, tid >> 3, BM);
+        const char* w_ptr[W_IT];
 #pragma unroll
-            for (int it = 0; it < A_IT; ++it) {
-                const bool ok = rows.ok[it] && k < p.K && live;
-                const char* src = ok ? p.A + (rows.off[it] + k) * sizeof(T) : zsrc;
+        for (int it = 0; it < W_IT; ++it)
+            w_ptr[it] = p.W + ((long)(n0 + it * (NT / 8) + (tid >> 3)) * p.Kpad + lchunk * EPC) * sizeof(T);
+        int kc = kt0 * BK + lchunk * EPC, tap = 0;
+        if (CONV) {
+            tap = kc / p.Cin;
+            kc -= tap * p.Cin;
+        }
+
+        // Fast conv path (Cin a multiple of the k-tile): the tap is the same for every thread of a k-tile
+        // and changes only every Cin/BK tiles, so the per-row source offsets are recomputed only then.
+        const bool conv_fast = CONV && (p.Cin % BK == 0);
+        long cur[A_IT];
+        bool cur_ok[A_IT];
+        int c0 = 0;  // channel offset of the current k-tile inside its tap
+        if (conv_fast) {
+            c0 = kc - lchunk * EPC;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) cur_ok[it] = conv_src<A_IT>(rows, p, it, tap, lchunk * EPC, cur[it]);
+        }
+
+        auto issue = [&](int kt, int stage) {
+            char* sa = smem + stage * STAGE_BYTES + lds_wave;
+            char* sw = sa + BM * 128;
+            const bool live = kt < kt1;
+            if (conv_fast) {
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) {
+                    const char* src = (cur_ok[it] && live) ? p.A + (cur[it] + c0) * sizeof(T) : zsrc;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
+                }
+                c0 += BK;
+                if (c0 == p.Cin) {
+                    c0 = 0;
+                    ++tap;
+#pragma unroll
+                    for (int it = 0; it < A_IT; ++it) cur_ok[it] = conv_src<A_IT>(rows, p, it, tap, lchunk * EPC, cur[it]);
+                }
+            } else if (CONV) {
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) {
+                    long e;
+                    const bool ok = conv_src<A_IT>(rows, p, it, tap, kc, e) && live;
+                    const char* src = ok ? p.A + e * sizeof(T) : zsrc;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
+                }
+                kc += BK;
+                while (kc >= p.Cin) {
+                    kc -= p.Cin;
+                    ++tap;
+                }
+            } else {
+                const int k = kt * BK + lchunk * EPC;
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) {
+                    const bool ok = rows.ok[it] && k < p.K && live;
+                    const char* src = ok ? p.A + (rows.off[it] + k) * sizeof(T) : zsrc;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < W_IT; ++it) {
+                const char* src = live ? w_ptr[it] + (long)kt * BK * sizeof(T) : zsrc;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(sw + it * (NT * 16)), 16, 0, 0);
+            }
+        };
+
+        f32x4 acc[FM][4];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // prologue: tiles kt0 .. kt0+STAGES-2 in flight (out-of-range tiles are issued as zero loads so
+        // that every wave's vmcnt arithmetic stays uniform)
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s) issue(kt0 + s, s);
+
+        int stage = 0;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            // tile kt has landed once at most (STAGES-2) younger tiles are outstanding; the barrier makes
+            // every wave's share visible and retires all reads of the stage refilled below
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LOADS) : "memory");
+            __builtin_amdgcn_s_barrier();
+            int nstage = stage + STAGES - 1;
+            if (nstage >= STAGES) nstage -= STAGES;
+            issue(kt + STAGES - 1, nstage);
+            const char* sa = smem + stage * STAGE_BYTES;
+            mma_tile<T, FM>(acc, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq);
+            if (++stage == STAGES) stage = 0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        if (p.streamk && !(kt0 == 0 && kt1 == nkt)) {
+            // Partial tile.  Every block that holds a k-run of this tile stores its accumulators, in
+            // register order, write-through (sc1: the bytes are at memory scope once vmcnt drains, no
+            // release fence needed) and then draws a ticket; the block that draws the last one sums the
+            // slabs in block order (so the result does not depend on arrival order) and runs the epilogue.
+            const long ut0 = (long)tile_id * nkt;
+            const long U = (long)ntm * ntn * nkt;
+            const int G = gridDim.x;
+            const int g_first = (int)(((ut0 + 1) * G + U - 1) / U) - 1;    // block whose run holds unit ut0
+            const int g_last = (int)(((ut0 + nkt) * G + U - 1) / U) - 1;  // ... and the tile's last unit
+            constexpr long SLAB = (long)BM * BN;                           // floats
+            {
+                float* slab = p.slabs + (2L * sk_g + (kt0 == 0 ? 1 : 0)) * SLAB;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)(SLAB * 4), 0x00020000);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs,
+                                                               ((i * 4 + j) * NT + tid) * 16, 0, 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* ticket = reinterpret_cast<int*>(smem);
+            if (tid == 0)
+                *ticket = __hip_atomic_fetch_add(p.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const bool last = *ticket == g_last - g_first;
+            if (!last) continue;
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(p.counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            for (int c = g_first; c <= g_last; ++c) {
+                const float* slab = p.slabs + (2L * c + (c == g_first ? 1 : 0)) * SLAB;
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(slab + ((i * 4 + j) * NT + tid) * 4);
+                        acc[i][j] = c == g_first ? v : acc[i][j] + v;
+                    }
             }
         }
-#pragma unroll
-        for (int it = 0; it < W_IT; ++it) {
-            const char* src = live ? w_ptr[it] + (long)kt * BK * sizeof(T) : zsrc;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sw + it * (NT * 16)), 16, 0, 0);
-        }
-    };
-
-    f32x4 acc[FM][4];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int fr = lane & 15, fq = lane >> 4;
-
-    // prologue: tiles kt0 .. kt0+STAGES-2 in flight (out-of-range tiles are issued as zero loads so
-    // that every wave's vmcnt arithmetic stays uniform)
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s) issue(kt0 + s, s);
-
-    int stage = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        // tile kt has landed once at most (STAGES-2) younger tiles are outstanding; the barrier makes
-        // every wave's share visible and retires all reads of the stage refilled below
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LOADS) : "memory");
-        __builtin_amdgcn_s_barrier();
-        int nstage = stage + STAGES - 1;
-        if (nstage >= STAGES) nstage -= STAGES;
-        issue(kt + STAGES - 1, nstage);
-        const char* sa = smem + stage * STAGE_BYTES;
-        mma_tile<T, FM>(acc, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq);
-        if (++stage == STAGES) stage = 0;
+        epilogue<T, FM>(p, acc, m0 + wm * 16 * FM, n0 + wn * 64, fr, fq, blockIdx.y);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    epilogue<T, FM>(p, acc, m0 + wm * 16 * FM, n0 + wn * 64, fr, fq, blockIdx.y);
 }
 
 // Two entry kernels over the same body so that profiles tell the dense GEMMs (Linear / conv1x1) from
@@ -593,13 +668,14 @@ template <typename K> int launch_kernel(K kfn, bool& attr_done, const TileInfo& 
         attr_done = true;
     }
     const int ntm = (a.M + t.bm - 1) / t.bm, ntn = (a.N + t.bn - 1) / t.bn;
-    dim3 grid(ntm * ntn, a.splitk > 1 ? a.splitk : 1, 1);
+    dim3 grid(a.streamk ? a.streamk : ntm * ntn, a.splitk > 1 ? a.splitk : 1, 1);
     hipLaunchKernelGGL(kfn, grid, dim3(t.threads), t.lds, stream, a);
     return dm_check_launch();
 }
 
 template <typename T, int BM, int BN, int WM, int WN> int launch_reg(const GemmArgs& a, hipStream_t s) {
     static bool done = false;
+    if (a.streamk) return DM_ERR_ARG;  // the work-list form exists for the direct-to-LDS tiles only
     const TileInfo t{BM, BN, WM * WN * 64, 2 * (BM + BN) * 128};
     return launch_kernel(gemm_reg_kernel<T, BM, BN, WM, WN>, done, t, a, s);
 }
@@ -727,6 +803,21 @@ extern "C" long dm_gemm_workspace_bytes(int M, int N, int splitk) {
     return splitk > 1 ? (long)splitk * M * N * (long)sizeof(float) : 0;
 }
 
+namespace {
+long streamk_counter_bytes(int tile, int M, int N) {
+    int bm, bn;
+    if (tile_dims(tile, &bm, &bn)) return -1;
+    const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    return (tiles * 4 + 255) / 256 * 256;
+}
+}  // namespace
+
+extern "C" long dm_gemm_streamk_workspace_bytes(int tile, int M, int N, int blocks) {
+    int bm, bn;
+    if (tile_dims(tile, &bm, &bn) || blocks <= 0) return -1;
+    return streamk_counter_bytes(tile, M, N) + 2L * blocks * bm * bn * (long)sizeof(float);
+}
+
 extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     if (!d || !d->a || !d->w || !d->c) return DM_ERR_ARG;
     if (d->m <= 0 || d->n <= 0 || d->k <= 0) return DM_ERR_ARG;
@@ -755,12 +846,22 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
 
     int tile = d->tile, splitk = d->splitk;
     if (tile == DM_TILE_AUTO) dm_gemm_plan(d->dtype, d->m, d->n, d->k, d->epi, &tile, &splitk);
+    int bm, bn;
+    if (tile_dims(tile, &bm, &bn)) return DM_ERR_ARG;
+    int streamk = 0;
+    if (splitk < 0) {
+        // work-list form: -splitk blocks share the (tile, k-tile) list; never more blocks than list entries
+        const long units = (long)((d->m + bm - 1) / bm) * ((d->n + bn - 1) / bn) * (d->kpad / bk);
+        streamk = (long)-splitk < units ? -splitk : (int)units;
+        splitk = 1;
+        if (!d->workspace || (reinterpret_cast<uintptr_t>(d->workspace) & 255u) ||
+            d->workspace_bytes < dm_gemm_streamk_workspace_bytes(tile, d->m, d->n, streamk))
+            return DM_ERR_ARG;
+    }
     if (splitk < 1) splitk = 1;
     if (splitk > 1 && (d->epi != DM_EPI_PLAIN || !d->workspace ||
                        d->workspace_bytes < dm_gemm_workspace_bytes(d->m, d->n, splitk)))
         return DM_ERR_ARG;
-    int bm, bn;
-    if (tile_dims(tile, &bm, &bn)) return DM_ERR_ARG;
     // packed weights must cover every tile row that will be read
     if (d->npad < ((d->n + bn - 1) / bn) * bn) return DM_ERR_ARG;
 
@@ -782,6 +883,10 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     a.epi = d->epi;
     a.splitk = splitk;
     a.partial = static_cast<float*>(d->workspace);
+    a.streamk = streamk;
+    a.counters = static_cast<int*>(d->workspace);
+    a.slabs = streamk ? reinterpret_cast<float*>(static_cast<char*>(d->workspace) + streamk_counter_bytes(tile, d->m, d->n))
+                      : nullptr;
 
     int rc = d->dtype == DM_F32 ? launch_typed<float>(a, tile, stream) : launch_typed<bf16_t>(a, tile, stream);
     if (rc != DM_OK) return rc;

@@ -98,6 +98,9 @@ class Engine:
         self.bk = 8 * self.epc
         self.arena = Arena(device)
         self.ws = torch.empty(64 << 20, dtype=torch.uint8, device=device)  # split-K slabs
+        # work-list (stream-K) GEMMs: arrival counters + accumulator slabs; the counters must read zero
+        # at every launch (the kernel leaves them zero), so this buffer is never shared with the slabs above
+        self.ws_sk = torch.zeros(160 << 20, dtype=torch.uint8, device=device)
         self.profile: Optional[dict] = None  # kernel class -> [events...] when profiling
         self._order_cache: Dict[Tuple[int, int, bool], torch.Tensor] = {}
         self.tile_override: Optional[Tuple[int, int]] = None
@@ -191,7 +194,7 @@ class Engine:
         tile, sk = C.c_int(0), C.c_int(1)
         if self.tile_override is not None:
             tile.value, sk.value = self.tile_override
-            if d.epi != _lib.EPI_PLAIN:
+            if d.epi != _lib.EPI_PLAIN and sk.value > 1:
                 sk.value = 1
         else:
             key = (m, pw.n, pw.k, d.conv, d.stride, d.up, d.epi, residual is not None, rowbias is not None)
@@ -205,6 +208,8 @@ class Engine:
         d.tile, d.splitk = tile.value, sk.value
         if sk.value > 1:
             self._bind_workspace(d, m, pw.n, sk.value)
+        elif sk.value < 0:
+            self._bind_streamk(d, tile.value, m, pw.n, -sk.value)
         with self._prof(klass, 2.0 * m * pw.n * (pw.k if conv is None else 9 * conv["cin_real"]),
                         f"m={m} n={pw.n} k={pw.k} tile={tile.value} sk={sk.value} epi={d.epi}"
                         + (f" s={d.stride} up={d.up}" if conv is not None else "")):
@@ -219,11 +224,22 @@ class Engine:
             self.ws = torch.empty(need * 2, dtype=torch.uint8, device=self.device)
         d.workspace, d.workspace_bytes = self.ws.data_ptr(), self.ws.numel()
 
+    def _bind_streamk(self, d: GemmDesc, tile: int, m: int, n: int, blocks: int):
+        need = self.lib.dm_gemm_streamk_workspace_bytes(tile, m, n, blocks)
+        if need < 0:
+            raise RuntimeError("stream-K needs a direct-to-LDS tile")
+        if need > self.ws_sk.numel():
+            if self.arena.frozen:
+                raise RuntimeError("stream-K workspace too small during graph capture")
+            self.ws_sk = torch.zeros(need * 2, dtype=torch.uint8, device=self.device)
+        d.workspace, d.workspace_bytes = self.ws_sk.data_ptr(), self.ws_sk.numel()
+
     # Candidate (tile, split-K) pairs are timed once per distinct problem on the real operands (the
     # launch is idempotent: it only rewrites the output) and the winner is cached for the process.
     _TUNE_TILES = (_lib.TILE_D256x128_S3, _lib.TILE_D128x128_S2, _lib.TILE_D256x64_S2, _lib.TILE_D128x64_S2,
                    _lib.TILE_D64x128_S3, _lib.TILE_D64x64_S4, _lib.TILE_D64x64_S2, _lib.TILE_D32x64_S4)
     _TUNE_SK = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)
+    _TUNE_STREAMK = (256, 512, 768, 1024)  # blocks sharing the (tile, k-tile) work list
 
     def _tune(self, d: GemmDesc, key):
         stream = self.stream
@@ -254,6 +270,21 @@ class Engine:
                     best, best_t = (tile, sk), t
                 if blocks * sk >= 2048 and sk > 1:  # already many rounds of blocks; more slices only add slab traffic
                     break
+            for grid in self._TUNE_STREAMK:
+                if grid >= 2 * blocks * nkt:
+                    break
+                d.tile, d.splitk = tile, -grid
+                self._bind_streamk(d, tile, d.m, d.n, grid)
+                if self.lib.dm_gemm(C.byref(d), stream) != 0:
+                    continue
+                e0.record()
+                for _ in range(3):
+                    self.lib.dm_gemm(C.byref(d), stream)
+                e1.record()
+                e1.synchronize()
+                t = e0.elapsed_time(e1)
+                if t < best_t:
+                    best, best_t = (tile, -grid), t
         if best is not None:
             self.tuned[key] = best
         return best

@@ -80,14 +80,20 @@ typedef struct DmGemmDesc {
     int hin, win, hout, wout, cin, stride, up;
     int epi;
     int tile;             /* DM_TILE_* (DM_TILE_AUTO: library chooses tile and split) */
-    int splitk;           /* used when tile != AUTO */
-    void* workspace;      /* split-K slabs, >= dm_gemm_workspace_bytes() */
+    int splitk;           /* used when tile != AUTO.  > 1: k is cut into `splitk` slices, one block each, summed by a
+                           * second launch (plain epilogue only).  < 0: work-list form for the direct-to-LDS tiles:
+                           * -splitk blocks share the (output tile, k-tile) list in equal runs; a tile cut between
+                           * blocks is summed, in block order, by the last of them to arrive (any epilogue). */
+    void* workspace;      /* split-K slabs, >= dm_gemm_workspace_bytes(); work-list form: 256-byte aligned,
+                           * >= dm_gemm_streamk_workspace_bytes(), whose leading arrival counters must read zero
+                           * at launch (the kernel leaves them zero) - do not share it with split-K slabs */
     long workspace_bytes;
 } DmGemmDesc;
 
 int dm_gemm(const DmGemmDesc* d, hipStream_t stream);
 void dm_gemm_plan(int dtype, int m, int n, int k, int epi, int* tile, int* splitk);
 long dm_gemm_workspace_bytes(int m, int n, int splitk);
+long dm_gemm_streamk_workspace_bytes(int tile, int m, int n, int blocks); /* -1: tile has no work-list form */
 /* order[p] = source weight row of packed row p (or -1 for a zero row), for p in [0, npad). */
 int dm_pack_weight_order(int n, int npad, int geglu, int* order_host);
 

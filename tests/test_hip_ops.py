@@ -84,6 +84,63 @@ def test_gemm_splitk_and_strides(eng, splitk):
     assert float(cbuf[:, :64].abs().max()) == 0.0 and float(cbuf[:, 64 + n:].abs().max()) == 0.0
 
 
+DMA_TILES = tuple(t for t in _lib.ALL_TILES if t >= _lib.TILE_D128x128_S2)
+
+
+@pytest.mark.parametrize("tile", DMA_TILES)
+@pytest.mark.parametrize("blocks", [1, 7, 64, 300])
+def test_gemm_streamk(eng, tile, blocks):
+    """Work-list form: `blocks` blocks share the (tile, k-tile) list; tiles cut between blocks are summed by
+    the last block to arrive.  Two launches in a row: the arrival counters must come back to zero, and the
+    result must not depend on arrival order (bitwise equal)."""
+    m, n, k = 200, 640, 1280
+    a = tin("k.a", (m, k)); w = tin("k.w", (n, k), scale=1 / math.sqrt(k)); b = tin("k.b", (n,))
+    rb = tin("k.rb", (2, n)); r = tin("k.r", (m, n))
+    lin = torch.nn.Linear(k, n)
+    with torch.no_grad():
+        lin.weight.copy_(w); lin.bias.copy_(b)
+    pw = eng.pack_linear(lin)
+    eng.tile_override = (tile, -blocks)
+    ad, rd = up(eng, a), up(eng, r)
+    outs = [eng.gemm(ad, pw, rowbias=rb.to(eng.device), rows_per_batch=100, residual=rd).clone() for _ in range(2)]
+    ref = rnd(a, eng.dtype) @ rnd(w, eng.dtype).t() + b + rb.repeat_interleave(100, 0) + rnd(r, eng.dtype)
+    assert max_rel(outs[0].float(), ref) < tol(eng.dtype)
+    assert torch.equal(outs[0], outs[1])
+    assert int(eng.ws_sk[:4096].max()) == 0
+
+
+@pytest.mark.parametrize("blocks", [3, 50, 256])
+def test_gemm_streamk_geglu_and_conv(eng, blocks):
+    m, c = 150, 320
+    a = tin("kg.a", (m, c)); w = tin("kg.w", (8 * c, c), scale=1 / math.sqrt(c)); b = tin("kg.b", (8 * c,))
+    lin = torch.nn.Linear(c, 8 * c)
+    with torch.no_grad():
+        lin.weight.copy_(w); lin.bias.copy_(b)
+    pw = eng.pack_linear(lin, geglu=True)
+    eng.tile_override = (_lib.TILE_D64x128_S3, -blocks)
+    out = eng.gemm(up(eng, a), pw)
+    y = rnd(a, eng.dtype) @ rnd(w, eng.dtype).t() + b
+    v, g = y.chunk(2, dim=-1)
+    assert max_rel(out.float(), v * F.gelu(g)) < tol(eng.dtype)
+    bsz = 2
+    for cin, cout, h, wd, stride, upx in ((320, 320, 8, 8, 1, 0), (64, 128, 9, 7, 2, 0), (128, 64, 6, 5, 1, 1), (4, 320, 8, 8, 1, 0)):
+        x = tin("kc.x", (bsz, cin, h, wd)); wt = tin("kc.w", (cout, cin, 3, 3), scale=1 / math.sqrt(9 * cin)); bias = tin("kc.b", (cout,))
+        conv = torch.nn.Conv2d(cin, cout, 3, stride=stride, padding=1)
+        with torch.no_grad():
+            conv.weight.copy_(wt); conv.bias.copy_(bias)
+        pc = eng.pack_conv3x3(conv)
+        rows = eng.nchw_to_rows(x.to(eng.device), cpad=pc.conv_cin)
+        xin = F.interpolate(rnd(x, eng.dtype), scale_factor=2, mode="nearest") if upx else rnd(x, eng.dtype)
+        ref = F.conv2d(xin, rnd(wt, eng.dtype), bias, stride=stride, padding=1)
+        ho, wo = ref.shape[2], ref.shape[3]
+        for tile in (_lib.TILE_D128x64_S2, _lib.TILE_D32x64_S4):
+            eng.tile_override = (tile, -blocks)
+            out = eng.gemm(rows, pc, conv=dict(batch=bsz, hin=h, win=wd, hout=ho, wout=wo, stride=stride, up=upx, cin_real=cin))
+            assert max_rel(eng.rows_to_nchw(out, bsz, cout, ho, wo), ref) < tol(eng.dtype), (cin, cout, stride, upx, tile)
+    eng.tile_override = None
+    assert int(eng.ws_sk[:4096].max()) == 0
+
+
 def test_gemm_geglu(eng):
     m, c = 150, 320
     a = tin("gg.a", (m, c)); w = tin("gg.w", (8 * c, c), scale=1 / math.sqrt(c)); b = tin("gg.b", (8 * c,))
