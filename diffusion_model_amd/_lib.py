@@ -48,6 +48,7 @@ class GemmDesc(C.Structure):
         ("tile", C.c_int),
         ("splitk", C.c_int),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_long),
+        ("stats", C.c_void_p), ("ld_stats", C.c_long),
     ]
 
 
@@ -58,6 +59,9 @@ _PROTOS = {
     "dm_gemm_plan": (None, [_i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "dm_gemm_workspace_bytes": (C.c_long, [_i, _i, _i]),
     "dm_gemm_streamk_workspace_bytes": (C.c_long, [_i, _i, _i, _i]),
+    "dm_gemm_stats_supported": (C.c_int, [_i, _i, _i]),
+    "dm_groupnorm_apply_sums": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _f, _i, _vp]),
+    "dm_zero": (C.c_int, [_vp, _l, _vp]),
     "dm_pack_weight_order": (C.c_int, [_i, _i, _i, _vp]),
     "dm_groupnorm_stats": (C.c_int, [_vp, _l, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "dm_groupnorm_apply": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp]),

@@ -308,6 +308,11 @@ extern "C" int dm_gather_row(const float* table, long ld, const int* index, floa
     return dm_check_launch();
 }
 
+extern "C" int dm_zero(void* ptr, long bytes, hipStream_t stream) {
+    if (!ptr || bytes <= 0) return DM_ERR_ARG;
+    return hipMemsetAsync(ptr, 0, (size_t)bytes, stream) == hipSuccess ? DM_OK : DM_ERR_LAUNCH;
+}
+
 extern "C" int dm_advance_counter(int* counter, int delta, hipStream_t stream) {
     if (!counter) return DM_ERR_ARG;
     hipLaunchKernelGGL(advance_counter_kernel, dim3(1), dim3(64), 0, stream, counter, delta);

@@ -47,6 +47,8 @@ struct GemmArgs {
     int epi;
     int splitk;
     float* partial;
+    double* stats;  // per-channel (sum, sumsq) of the stored output, [batch][2][ld_stats], atomically accumulated
+    long ld_stats;
     int streamk;    // stream-K: number of blocks sharing the (tile, k-tile) work list; 0 = one tile per block
     int* counters;  // stream-K: one arrival counter per output tile, zero on entry, left zero
     float* slabs;   // stream-K: 2 accumulator slabs per block
@@ -259,6 +261,15 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FM][4],
                     }
                 }
             }
+            if (p.stats) {
+                // keep the value as stored (after rounding) in the accumulator for the statistics pass below
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float v = o[q];
+                    if constexpr (sizeof(T) == 2) v = bf16_to_f32(f32_to_bf16(v));
+                    acc[i][2 * h + (q >> 2)][q & 3] = v;
+                }
+            }
             if (p.epi == DM_EPI_NCHW_F32) {
                 const int hw = p.rows_per_batch;
                 const int b = m / hw, pix = m - b * hw;
@@ -278,6 +289,54 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FM][4],
                     *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
                 }
             }
+        }
+    }
+    if (p.stats && mrow0 < p.M) {
+        // GroupNorm statistics of the tensor just written: per-channel sum and sum of squares over this
+        // wave's rows, which all belong to one sample and are all valid (checked on the host).  Four columns
+        // at a time (few live registers): reduce-scatter over lane bits 0-1, all-reduce over bits 2-3, then
+        // the lanes with fr>>2 == j own column 4*j + (fr&3) = fr.
+        float own_s = 0.f, own_q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[2][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[0][r] = v[1][r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                if (mrow0 + i * 16 < p.M) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[0][r] += acc[i][j][r];
+                        v[1][r] = fmaf(acc[i][j][r], acc[i][j][r], v[1][r]);
+                    }
+                }
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+#pragma unroll
+                for (int half = 2; half >= 1; half >>= 1) {
+                    const bool upper = (fr & half) != 0;
+#pragma unroll
+                    for (int q = 0; q < half; ++q) {
+                        const float keep = upper ? v[w][q + half] : v[w][q];
+                        const float send = upper ? v[w][q] : v[w][q + half];
+                        v[w][q] = keep + __shfl_xor(send, half);
+                    }
+                }
+                v[w][0] += __shfl_xor(v[w][0], 4);
+                v[w][0] += __shfl_xor(v[w][0], 8);
+            }
+            if ((fr >> 2) == j) {
+                own_s = v[0][0];
+                own_q = v[1][0];
+            }
+        }
+        const int n = ncol0 + fr;
+        if (n < p.N) {
+            const long b = mrow0 / p.rows_per_batch;
+            double* dst = p.stats + (b * 2) * p.ld_stats + n;
+            atomicAdd(dst, (double)own_s);
+            atomicAdd(dst + p.ld_stats, (double)own_q);
         }
     }
 }
@@ -710,6 +769,19 @@ template <typename T> int launch_typed(const GemmArgs& a, int cfg, hipStream_t s
     }
 }
 
+// rows of the output tile owned by one wave
+int tile_wave_rows(int cfg) {
+    switch (cfg) {
+        case DM_TILE_64x64: case DM_TILE_32x64: case DM_TILE_D64x64_S4: case DM_TILE_D64x64_S2: case DM_TILE_D32x64_S4:
+            return 16;
+        case DM_TILE_64x128: case DM_TILE_D64x128_S3: case DM_TILE_D64x128_S4: case DM_TILE_D128x64_S4:
+        case DM_TILE_D128x64_S2:
+            return 32;
+        case DM_TILE_D256x256_S2: return 128;
+        default: return 64;
+    }
+}
+
 int tile_dims(int cfg, int* bm, int* bn) {
     switch (cfg) {
         case DM_TILE_128x128: case DM_TILE_D128x128_S2: case DM_TILE_D128x128_S3: *bm = 128; *bn = 128; return 0;
@@ -812,6 +884,12 @@ long streamk_counter_bytes(int tile, int M, int N) {
 }
 }  // namespace
 
+extern "C" int dm_gemm_stats_supported(int tile, int rows_per_batch, int splitk) {
+    int bm, bn;
+    if (tile_dims(tile, &bm, &bn) || rows_per_batch <= 0 || splitk > 1) return 0;
+    return rows_per_batch % tile_wave_rows(tile) == 0;
+}
+
 extern "C" long dm_gemm_streamk_workspace_bytes(int tile, int M, int N, int blocks) {
     int bm, bn;
     if (tile_dims(tile, &bm, &bn) || blocks <= 0) return -1;
@@ -842,12 +920,17 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
         return DM_ERR_ARG;
     }
     if (d->epi == DM_EPI_GEGLU && (!d->bias || d->n % 64 || d->rowbias || d->r)) return DM_ERR_ARG;
-    if ((d->rowbias || d->epi == DM_EPI_NCHW_F32) && d->rows_per_batch <= 0) return DM_ERR_ARG;
+    if ((d->rowbias || d->epi == DM_EPI_NCHW_F32 || d->stats) && d->rows_per_batch <= 0) return DM_ERR_ARG;
+    if (d->stats && (d->epi != DM_EPI_PLAIN || (reinterpret_cast<uintptr_t>(d->stats) & 7u) || d->ld_stats < d->n))
+        return DM_ERR_ARG;
 
     int tile = d->tile, splitk = d->splitk;
     if (tile == DM_TILE_AUTO) dm_gemm_plan(d->dtype, d->m, d->n, d->k, d->epi, &tile, &splitk);
     int bm, bn;
     if (tile_dims(tile, &bm, &bn)) return DM_ERR_ARG;
+    // fused statistics: a wave's rows must lie inside one sample, and the separate split-K reduction
+    // launch does not produce them
+    if (d->stats && (d->rows_per_batch % tile_wave_rows(tile) || d->m % d->rows_per_batch || splitk > 1)) return DM_ERR_ARG;
     int streamk = 0;
     if (splitk < 0) {
         // work-list form: -splitk blocks share the (tile, k-tile) list; never more blocks than list entries
@@ -883,6 +966,8 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     a.epi = d->epi;
     a.splitk = splitk;
     a.partial = static_cast<float*>(d->workspace);
+    a.stats = d->stats;
+    a.ld_stats = d->ld_stats;
     a.streamk = streamk;
     a.counters = static_cast<int*>(d->workspace);
     a.slabs = streamk ? reinterpret_cast<float*>(static_cast<char*>(d->workspace) + streamk_counter_bytes(tile, d->m, d->n))

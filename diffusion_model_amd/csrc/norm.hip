@@ -123,6 +123,7 @@ template <typename T>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y,
                                                                long ldy, int hw, int c, int groups,
                                                                const float* __restrict__ partial, int nsplit,
+                                                               const double* __restrict__ sums, long ld_sums,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, int silu,
                                                                int rows_per_block) {
@@ -139,10 +140,19 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
     for (int item = tid; item < groups * 8; item += GN_THREADS) {
         const int grp = item >> 3, part = item & 7;
         double a = 0.0, d = 0.0;
-        for (int sp = part; sp < nsplit; sp += 8) {
-            const float* src = partial + (((long)b * nsplit + sp) * groups + grp) * 2;
-            a += (double)src[0];
-            d += (double)src[1];
+        if (sums) {
+            // per-channel sums accumulated by the kernel that wrote x
+            const double* src = sums + (long)b * 2 * ld_sums;
+            for (int ch = grp * cpg + part; ch < (grp + 1) * cpg; ch += 8) {
+                a += src[ch];
+                d += src[ld_sums + ch];
+            }
+        } else {
+            for (int sp = part; sp < nsplit; sp += 8) {
+                const float* src = partial + (((long)b * nsplit + sp) * groups + grp) * 2;
+                a += (double)src[0];
+                d += (double)src[1];
+            }
         }
         sub[grp][part][0] = a;
         sub[grp][part][1] = d;
@@ -294,8 +304,8 @@ template <typename T> int gn_stats_launch(const void* x, long ldx, int batch, in
 
 template <typename T>
 int gn_apply_launch(const void* x, long ldx, void* y, long ldy, int batch, int hw, int c, int groups,
-                    const float* partial, int nsplit, const float* gamma, const float* beta, float eps, int silu,
-                    hipStream_t s) {
+                    const float* partial, int nsplit, const double* sums, long ld_sums, const float* gamma,
+                    const float* beta, float eps, int silu, hipStream_t s) {
     const GnGeom g = gn_geom<T>(c);
     if (g.slots > GN_MAX_SLOTS || c > GN_MAX_C) return DM_ERR_ARG;
     // enough blocks to fill the chip, at least rpi rows each
@@ -305,8 +315,8 @@ int gn_apply_launch(const void* x, long ldx, void* y, long ldy, int batch, int h
     if (rows_per_block < g.rpi) rows_per_block = g.rpi;
     const int nb = (hw + rows_per_block - 1) / rows_per_block;
     hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(nb, batch), dim3(GN_THREADS), 2 * c * sizeof(float), s,
-                       static_cast<const T*>(x), ldx, static_cast<T*>(y), ldy, hw, c, groups, partial, nsplit, gamma,
-                       beta, eps, silu, rows_per_block);
+                       static_cast<const T*>(x), ldx, static_cast<T*>(y), ldy, hw, c, groups, partial, nsplit, sums,
+                       ld_sums, gamma, beta, eps, silu, rows_per_block);
     return dm_check_launch();
 }
 
@@ -354,8 +364,19 @@ extern "C" int dm_groupnorm_apply(const void* x, long ldx, void* y, long ldy, in
         groups <= 0 || groups > 64 || c % groups || nsplit <= 0)
         return DM_ERR_ARG;
     return dtype == DM_F32
-               ? gn_apply_launch<float>(x, ldx, y, ldy, batch, hw, c, groups, partial, nsplit, gamma, beta, eps, silu, stream)
-               : gn_apply_launch<bf16_t>(x, ldx, y, ldy, batch, hw, c, groups, partial, nsplit, gamma, beta, eps, silu, stream);
+               ? gn_apply_launch<float>(x, ldx, y, ldy, batch, hw, c, groups, partial, nsplit, nullptr, 0, gamma, beta, eps, silu, stream)
+               : gn_apply_launch<bf16_t>(x, ldx, y, ldy, batch, hw, c, groups, partial, nsplit, nullptr, 0, gamma, beta, eps, silu, stream);
+}
+
+extern "C" int dm_groupnorm_apply_sums(const void* x, long ldx, void* y, long ldy, int batch, int hw, int c, int groups,
+                                       int dtype, const double* sums, long ld_sums, const float* gamma,
+                                       const float* beta, float eps, int silu, hipStream_t stream) {
+    if (!norm_args_ok(x, ldx, y, ldy, c, dtype) || !y || !sums || ld_sums < c || !gamma || !beta || batch <= 0 ||
+        hw <= 0 || groups <= 0 || groups > 64 || c % groups)
+        return DM_ERR_ARG;
+    return dtype == DM_F32
+               ? gn_apply_launch<float>(x, ldx, y, ldy, batch, hw, c, groups, nullptr, 0, sums, ld_sums, gamma, beta, eps, silu, stream)
+               : gn_apply_launch<bf16_t>(x, ldx, y, ldy, batch, hw, c, groups, nullptr, 0, sums, ld_sums, gamma, beta, eps, silu, stream);
 }
 
 extern "C" int dm_layernorm(const void* x, long ldx, void* y, long ldy, int rows, int c, int dtype, const float* gamma,

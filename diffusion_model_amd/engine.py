@@ -101,6 +101,14 @@ class Engine:
         # work-list (stream-K) GEMMs: arrival counters + accumulator slabs; the counters must read zero
         # at every launch (the kernel leaves them zero), so this buffer is never shared with the slabs above
         self.ws_sk = torch.zeros(160 << 20, dtype=torch.uint8, device=device)
+        # GroupNorm statistics accumulated by the producing GEMM: per-channel fp64 (sum, sumsq), [batch][2][C].
+        # Regions are handed out bump-style per forward and the used prefix is zeroed by reset().
+        self.stats_buf = torch.zeros(8 << 20, dtype=torch.float64, device=device)
+        self._stats_off = 0    # elements handed out since the last reset
+        self._stats_dirty = 0  # high-water mark of elements that may be non-zero
+        self._gn_shared: List[dict] = []      # buffers with several producers (skip-concat buffers)
+        self._gn_auto: Dict[int, dict] = {}   # data_ptr -> record of a tensor written by one GEMM
+        self.fuse_gn_stats = os.environ.get("DM_FUSE_GN_STATS", "1") == "1"
         self.profile: Optional[dict] = None  # kernel class -> [events...] when profiling
         self._order_cache: Dict[Tuple[int, int, bool], torch.Tensor] = {}
         self.tile_override: Optional[Tuple[int, int]] = None
@@ -121,7 +129,62 @@ class Engine:
         dtype = dtype or self.dtype
         if persistent:
             return torch.empty(rows, cols, dtype=dtype, device=self.device)
-        return self.arena.alloc(rows, cols, dtype)
+        t = self.arena.alloc(rows, cols, dtype)
+        self._gn_auto.pop(t.data_ptr(), None)  # whatever lived at this address before is gone
+        return t
+
+    def reset(self):
+        """Start of a forward: recycle the activation arena and clear the statistics region used so far."""
+        self.arena.reset()
+        self._gn_shared.clear()
+        self._gn_auto.clear()
+        if self._stats_dirty:
+            check(self.lib.dm_zero(self.stats_buf.data_ptr(), self._stats_dirty * 8, self.stream), "zero")
+        self._stats_off = 0
+
+    # ------------------------------------------------------------------ fused GroupNorm statistics
+    def _stats_alloc(self, batch: int, c: int) -> torch.Tensor:
+        n = _rup(batch * 2 * c, 32)
+        if self._stats_off + n > self.stats_buf.numel():
+            if self.arena.frozen:
+                raise RuntimeError("statistics buffer exhausted during graph capture; run one eager step first")
+            self.stats_buf = torch.zeros(max(2 * self.stats_buf.numel(), n), dtype=torch.float64, device=self.device)
+            self._stats_off = self._stats_dirty = 0
+        t = self.stats_buf[self._stats_off:self._stats_off + batch * 2 * c].view(batch, 2, c)
+        self._stats_off += n
+        self._stats_dirty = max(self._stats_dirty, self._stats_off)
+        return t
+
+    def gn_register(self, buf: torch.Tensor, batch: int):
+        """Announce a buffer whose channel slices are written by several GEMMs and then group-normalised whole."""
+        if not self.fuse_gn_stats:
+            return
+        self._gn_shared.append(dict(base=buf.data_ptr(), ld=buf.stride(0), cols=buf.shape[1], rows=buf.shape[0],
+                                    batch=batch, stats=self._stats_alloc(batch, buf.shape[1]), valid=True, parts=0))
+
+    def _gn_target(self, out: torch.Tensor, batch: int):
+        """(record, channel offset) that a GEMM writing `out` accumulates its statistics into."""
+        p, ld = out.data_ptr(), out.stride(0)
+        for rec in self._gn_shared:
+            if rec["ld"] == ld and rec["base"] <= p < rec["base"] + ld * self.esz and rec["rows"] == out.shape[0]:
+                return rec, (p - rec["base"]) // self.esz
+        rec = dict(base=p, ld=ld, cols=out.shape[1], rows=out.shape[0], batch=batch,
+                   stats=self._stats_alloc(batch, out.shape[1]), valid=True, parts=0)
+        self._gn_auto[p] = rec
+        return rec, 0
+
+    def _gn_lookup(self, x: torch.Tensor, batch: int):
+        p = x.data_ptr()
+        rec = self._gn_auto.get(p)
+        if rec is None:
+            for r in self._gn_shared:
+                if r["base"] == p:
+                    rec = r
+                    break
+        if (rec is None or not rec["valid"] or rec["ld"] != x.stride(0) or rec["cols"] != x.shape[1]
+                or rec["rows"] != x.shape[0] or rec["batch"] != batch or rec["parts"] != rec["cols"]):
+            return None
+        return rec
 
     # ------------------------------------------------------------------ weight packing
     def _order(self, n: int, npad: int, geglu: bool) -> torch.Tensor:
@@ -159,7 +222,10 @@ class Engine:
     # ------------------------------------------------------------------ operators
     def gemm(self, a: torch.Tensor, pw: PackedWeight, out: Optional[torch.Tensor] = None, *, bias=True,
              rowbias: Optional[torch.Tensor] = None, rows_per_batch: int = 0, residual: Optional[torch.Tensor] = None,
-             conv: Optional[dict] = None, nchw_out: Optional[torch.Tensor] = None, persistent=False) -> torch.Tensor:
+             conv: Optional[dict] = None, nchw_out: Optional[torch.Tensor] = None, persistent=False,
+             gn_batch: int = 0) -> torch.Tensor:
+        """``gn_batch`` > 0: a GroupNorm over ``gn_batch`` samples reads the output next; its statistics are
+        accumulated by this launch where the chosen tile allows it."""
         d = GemmDesc()
         if conv is not None:
             m = conv["batch"] * conv["hout"] * conv["wout"]
@@ -210,6 +276,18 @@ class Engine:
             self._bind_workspace(d, m, pw.n, sk.value)
         elif sk.value < 0:
             self._bind_streamk(d, tile.value, m, pw.n, -sk.value)
+        if gn_batch > 0 and self.fuse_gn_stats and nchw_out is None and not pw.geglu:
+            rec, ch_off = self._gn_target(out, gn_batch)
+            hw = m // gn_batch
+            ok = (m % gn_batch == 0 and (rows_per_batch in (0, hw)) and tile.value != _lib.TILE_AUTO
+                  and self.lib.dm_gemm_stats_supported(tile.value, hw, sk.value))
+            if ok:
+                d.stats = rec["stats"].data_ptr() + ch_off * 8
+                d.ld_stats = rec["cols"]
+                d.rows_per_batch = hw
+                rec["parts"] += pw.n
+            else:
+                rec["valid"] = False
         with self._prof(klass, 2.0 * m * pw.n * (pw.k if conv is None else 9 * conv["cin_real"]),
                         f"m={m} n={pw.n} k={pw.k} tile={tile.value} sk={sk.value} epi={d.epi}"
                         + (f" s={d.stride} up={d.up}" if conv is not None else "")):
@@ -240,6 +318,8 @@ class Engine:
                    _lib.TILE_D64x128_S3, _lib.TILE_D64x64_S4, _lib.TILE_D64x64_S2, _lib.TILE_D32x64_S4)
     _TUNE_SK = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)
     _TUNE_STREAMK = (256, 512, 768, 1024)  # blocks sharing the (tile, k-tile) work list
+    _TUNE_STREAMK_MULT = (2, 3, 4, 6, 8, 12, 16, 24)  # ... and whole multiples of the tile count
+    _TUNE_LEGACY_SK = True  # also try split-K with a separate reduction launch
 
     def _tune(self, d: GemmDesc, key):
         stream = self.stream
@@ -252,6 +332,8 @@ class Engine:
                 continue
             blocks = ((d.m + bm - 1) // bm) * ((d.n + bn - 1) // bn)
             for sk in self._TUNE_SK:
+                if sk > 1 and not self._TUNE_LEGACY_SK:
+                    break
                 if sk > 1 and (d.epi != _lib.EPI_PLAIN or nkt // sk < 2 or blocks * sk > 8192
                                or d.m * d.n * sk * 4 > (256 << 20)):
                     break
@@ -270,7 +352,10 @@ class Engine:
                     best, best_t = (tile, sk), t
                 if blocks * sk >= 2048 and sk > 1:  # already many rounds of blocks; more slices only add slab traffic
                     break
-            for grid in self._TUNE_STREAMK:
+            grids = set(self._TUNE_STREAMK) if self._TUNE_STREAMK else set()
+            if self._TUNE_STREAMK:
+                grids.update(blocks * s for s in self._TUNE_STREAMK_MULT if blocks * s <= 2048 and nkt // s >= 2)
+            for grid in sorted(grids):
                 if grid >= 2 * blocks * nkt:
                     break
                 d.tile, d.splitk = tile, -grid
@@ -292,8 +377,17 @@ class Engine:
     def groupnorm(self, x: torch.Tensor, batch: int, hw: int, gamma, beta, eps: float, silu: bool,
                   out: Optional[torch.Tensor] = None, groups: int = 32) -> torch.Tensor:
         c = x.shape[1]
+        rec = self._gn_lookup(x, batch)
         if out is None:
             out = self.new(batch * hw, c)
+        if rec is not None:
+            self._gn_auto.pop(x.data_ptr(), None)
+            with self._prof("groupnorm", float(batch * hw * c * self.esz * 2), f"b={batch} hw={hw} c={c} fused-stats"):
+                check(self.lib.dm_groupnorm_apply_sums(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), batch,
+                                                       hw, c, groups, self.dm, rec["stats"].data_ptr(), c,
+                                                       gamma.data_ptr(), beta.data_ptr(), eps, int(silu), self.stream),
+                      "groupnorm_apply_sums")
+            return out
         nsplit = max(1, min(hw // 16, max(8, self.gn_blocks // batch), 128))  # slabs of >= 16 rows
         part = self.arena.alloc(batch * nsplit, groups * 2, torch.float32)
         with self._prof("groupnorm", float(batch * hw * c * self.esz * 2), f"b={batch} hw={hw} c={c}"):

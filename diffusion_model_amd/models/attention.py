@@ -23,7 +23,7 @@ class SelfAttention(nn.Module):
         eng = engine_for(self, x)
         pk = rt.cached_pack(self, eng, rt.pack_self_attention)
         b, s, c = x.shape
-        eng.arena.reset()
+        eng.reset()
         rows = eng.to_rows(x)
         out = rt.run_self_attention(eng, pk, rows, b, s)
         return eng.from_rows(out, (b, s, c)).to(x.dtype)
@@ -46,7 +46,7 @@ class CrossAttention(nn.Module):
         pk = rt.cached_pack(self, eng, rt.pack_cross_attention)
         b, s, c = x.shape
         sk = y.shape[1]
-        eng.arena.reset()
+        eng.reset()
         kv = rt.context_kv(eng, pk, eng.to_rows(y), b, sk)
         out = rt.run_cross_attention(eng, pk, eng.to_rows(x), kv, b, s, sk)
         return eng.from_rows(out, (b, s, c)).to(x.dtype)

@@ -29,7 +29,7 @@ class ResidualBlock(nn.Module):
         eng = engine_for(self, feature)
         pk = rt.cached_pack(self, eng, rt.pack_residual_block)
         b, c, h, w = feature.shape
-        eng.arena.reset()
+        eng.reset()
         tproj = eng.linear_rows(time.float().contiguous(), pk.lt_w, pk.lt_b, silu_in=True)
         x = eng.nchw_to_rows(feature)
         out = rt.run_residual_block(eng, pk, x, b, h, w, tproj)
@@ -61,7 +61,7 @@ class AttentionBlock(nn.Module):
         pk = rt.cached_pack(self, eng, rt.pack_attention_block)
         b, c, h, w = x.shape
         sk = context.shape[1]
-        eng.arena.reset()
+        eng.reset()
         kv = rt.context_kv(eng, pk.ca, eng.to_rows(context), b, sk)
         rows = eng.nchw_to_rows(x)
         out = rt.run_attention_block(eng, pk, rows, b, h, w, kv, sk)

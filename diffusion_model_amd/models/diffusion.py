@@ -20,7 +20,7 @@ class FinalLayer(nn.Module):
         eng = engine_for(self, x)
         pk = rt.cached_pack(self, eng, rt.pack_final_layer)
         b, c, h, w = x.shape
-        eng.arena.reset()
+        eng.reset()
         a = eng.groupnorm(eng.nchw_to_rows(x), b, h * w, pk.gn_w, pk.gn_b, pk.gn_eps, silu=True)
         out = torch.empty(b, pk.cout, h, w, dtype=torch.float32, device=x.device)
         eng.gemm(a, pk.conv, nchw_out=out, rows_per_batch=h * w,
@@ -51,7 +51,7 @@ class Diffusion(nn.Module):
     def forward(self, latent: torch.Tensor, context: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
         eng = engine_for(self, latent)
         pk = rt.cached_pack(self, eng, rt.pack_diffusion)
-        eng.arena.reset()
+        eng.reset()
         kvs, sk = rt.precompute_context(eng, pk.unet, context)
         out = torch.empty(latent.shape[0], pk.final.cout, latent.shape[2], latent.shape[3], dtype=torch.float32,
                           device=latent.device)

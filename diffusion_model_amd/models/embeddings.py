@@ -17,7 +17,7 @@ class TimeEmbedding(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         eng = engine_for(self, x)
         pk = rt.cached_pack(self, eng, rt.pack_time_embedding)
-        eng.arena.reset()
+        eng.reset()
         t = eng.linear_rows(x.float().contiguous(), pk.w1, pk.b1, silu_in=False)
         out = torch.empty(x.shape[0], pk.w2.shape[0], dtype=torch.float32, device=x.device)
         eng.linear_rows(t, pk.w2, pk.b2, silu_in=True, out=out)

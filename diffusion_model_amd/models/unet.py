@@ -18,7 +18,7 @@ class Upsample(nn.Module):
         eng = engine_for(self, x)
         lp = rt.cached_pack(self, eng, lambda m, e: rt.pack_conv_layer(m.conv, e, up=True))
         b, c, h, w = x.shape
-        eng.arena.reset()
+        eng.reset()
         out, ho, wo = rt.run_conv_layer(eng, lp, eng.nchw_to_rows(x), b, h, w)
         return eng.rows_to_nchw(out, b, lp.cout, ho, wo).to(x.dtype)
 
@@ -43,7 +43,7 @@ def _conv2d_forward(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     eng = engine_for(conv, x)
     lp = rt.cached_pack(conv, eng, lambda m, e: rt._pack_stage([m], e)[0])
     b, c, h, w = x.shape
-    eng.arena.reset()
+    eng.reset()
     out, ho, wo = rt.run_conv_layer(eng, lp, eng.nchw_to_rows(x, cpad=rt._rup(c, 8)), b, h, w)
     return eng.rows_to_nchw(out, b, lp.cout, ho, wo).to(x.dtype)
 
@@ -91,7 +91,7 @@ class UNet(nn.Module):
         eng = engine_for(self, x)
         pk = rt.cached_pack(self, eng, rt.pack_unet)
         b, c, h, w = x.shape
-        eng.arena.reset()
+        eng.reset()
         kvs, sk = rt.precompute_context(eng, pk, context)
         tproj = eng.linear_rows(time.float().contiguous(), pk.lt_w, pk.lt_b, silu_in=True)
         rows = eng.nchw_to_rows(x, cpad=rt._rup(c, 8))

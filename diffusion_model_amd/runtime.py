@@ -160,10 +160,11 @@ def run_residual_block(eng: Engine, pk: NS, x, batch: int, h: int, w: int, tproj
     mark = eng.arena.mark()
     geom = dict(batch=batch, hin=h, win=w, hout=h, wout=w)
     a = eng.groupnorm(x, batch, hw, pk.gn1_w, pk.gn1_b, pk.gn1_eps, silu=True)
-    a = eng.gemm(a, pk.conv1, rowbias=tproj, rows_per_batch=hw, conv=dict(geom, cin_real=pk.cin))
+    a = eng.gemm(a, pk.conv1, rowbias=tproj, rows_per_batch=hw, conv=dict(geom, cin_real=pk.cin), gn_batch=batch)
     a = eng.groupnorm(a, batch, hw, pk.gn2_w, pk.gn2_b, pk.gn2_eps, silu=True)
     skip = x if pk.res is None else eng.gemm(x, pk.res)
-    eng.gemm(a, pk.conv2, out=out, residual=skip, conv=dict(geom, cin_real=pk.cout))
+    # the block output is group-normalised by whatever follows (ResidualBlock, AttentionBlock or FinalLayer)
+    eng.gemm(a, pk.conv2, out=out, residual=skip, conv=dict(geom, cin_real=pk.cout), gn_batch=batch)
     eng.arena.release(mark)
     return out
 
@@ -207,7 +208,7 @@ def run_attention_block(eng: Engine, pk: NS, x, batch: int, h: int, w: int, kv, 
     a = eng.layernorm(t, pk.ln3_w, pk.ln3_b, pk.ln3_eps)
     a = eng.gemm(a, pk.geglu1)
     t = eng.gemm(a, pk.geglu2, residual=t)
-    eng.gemm(t, pk.conv_out, out=out, residual=x)
+    eng.gemm(t, pk.conv_out, out=out, residual=x, gn_batch=batch)
     eng.arena.release(mark)
     return out
 
@@ -222,7 +223,7 @@ def run_conv_layer(eng: Engine, lp: NS, x, batch: int, h: int, w: int, out=None)
     ho, wo = _conv_out_hw(lp, h, w)
     geom = dict(batch=batch, hin=h, win=w, hout=ho, wout=wo, stride=lp.stride, up=int(lp.kind == "up"),
                 cin_real=lp.cin)
-    return eng.gemm(x, lp.w, out=out, conv=geom), ho, wo
+    return eng.gemm(x, lp.w, out=out, conv=geom, gn_batch=batch), ho, wo
 
 
 def _run_stage(eng: Engine, layers: List[NS], x, batch, h, w, tproj, kvs, sk, out):
@@ -274,6 +275,7 @@ def run_unet(eng: Engine, pk: NS, x, batch: int, h: int, w: int, tproj, kvs, sk:
             raise RuntimeError(f"skip connection size mismatch at decoder {i}: {(hx, wx)} vs {(hs, ws)}; "
                                "latent height/width must be divisible by 8")
         cat.append((eng.new(batch * hs * ws, cx + cs), cx, cs))
+        eng.gn_register(cat[-1][0], batch)  # both halves are written by GEMMs; the stage's first GroupNorm reads it whole
         cx, hx, wx = _stage_shape(st, cx + cs, hs, ws)
 
     hh, ww = h, w

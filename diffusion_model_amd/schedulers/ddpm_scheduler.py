@@ -173,7 +173,7 @@ class _DdpmLoop:
         B = self.shape[0]
         check(self.lib.dm_gather_row(self.temb.data_ptr(), 320, self.counter.data_ptr(), self.time_in.data_ptr(), 320,
                                      B, 320, s), "gather_row")
-        self.eng.arena.reset()
+        self.eng.reset()
         rt.diffusion_forward_into(self.eng, self.pk, self.x, self.time_in, self.kvs, self.sk, self.eps)
         check(self.lib.dm_ddpm_step(self.x.data_ptr(), self.eps.data_ptr(), self.noise.data_ptr(), self.x.data_ptr(),
                                     self.x.numel(), self.coef.data_ptr(), self.counter.data_ptr(), self.clip, s),
@@ -194,7 +194,7 @@ class _DdpmLoop:
             for i, nz in enumerate(noises):
                 self.noise[i].copy_(nz)
             self.counter.zero_()
-            self.eng.arena.reset()
+            self.eng.reset()
             self.kvs, _ = rt.precompute_context(self.eng, self.pk.unet, context, persistent=self.kvs is None,
                                                 out=self.kvs)
             done = 0

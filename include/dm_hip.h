@@ -88,23 +88,35 @@ typedef struct DmGemmDesc {
                            * >= dm_gemm_streamk_workspace_bytes(), whose leading arrival counters must read zero
                            * at launch (the kernel leaves them zero) - do not share it with split-K slabs */
     long workspace_bytes;
+    double* stats;        /* NULL, or per-channel sums of the STORED output for a following GroupNorm:
+                           * stats[(b*2 + 0)*ld_stats + n] += sum over the rows of sample b of c[m][n],
+                           * stats[(b*2 + 1)*ld_stats + n] += the same of c[m][n]^2 (atomic adds; the caller
+                           * zeroes the buffer).  Needs rows_per_batch, the plain epilogue, no split-K reduction
+                           * launch, and dm_gemm_stats_supported(tile, rows_per_batch, splitk) != 0. */
+    long ld_stats;
 } DmGemmDesc;
 
 int dm_gemm(const DmGemmDesc* d, hipStream_t stream);
 void dm_gemm_plan(int dtype, int m, int n, int k, int epi, int* tile, int* splitk);
 long dm_gemm_workspace_bytes(int m, int n, int splitk);
 long dm_gemm_streamk_workspace_bytes(int tile, int m, int n, int blocks); /* -1: tile has no work-list form */
+int dm_gemm_stats_supported(int tile, int rows_per_batch, int splitk);
 /* order[p] = source weight row of packed row p (or -1 for a zero row), for p in [0, npad). */
 int dm_pack_weight_order(int n, int npad, int geglu, int* order_host);
 
 /* GroupNorm (+ optional SiLU) over NHWC rows.  Replaces nn.GroupNorm(32, C) + F.silu
  * (blocks.py:58-59,68-69,128; diffusion.py:44-45).  Two launches: per-slab (sum, sumsq)
- * partials, then normalise.  partial: fp32 [batch][nsplit][groups][2]. */
+ * partials, then normalise.  partial: fp32 [batch][nsplit][groups][2].
+ * dm_groupnorm_apply_sums: one launch; the statistics come from the per-channel fp64 sums that
+ * dm_gemm accumulated while it wrote x (DmGemmDesc.stats: [batch][2][ld_sums]). */
 int dm_groupnorm_stats(const void* x, long ldx, int batch, int hw, int c, int groups, int dtype,
                        float* partial, int nsplit, hipStream_t stream);
 int dm_groupnorm_apply(const void* x, long ldx, void* y, long ldy, int batch, int hw, int c, int groups,
                        int dtype, const float* partial, int nsplit, const float* gamma, const float* beta,
                        float eps, int silu, hipStream_t stream);
+int dm_groupnorm_apply_sums(const void* x, long ldx, void* y, long ldy, int batch, int hw, int c, int groups,
+                            int dtype, const double* sums, long ld_sums, const float* gamma, const float* beta,
+                            float eps, int silu, hipStream_t stream);
 
 /* LayerNorm over the channel dimension of [rows][c].  Replaces nn.LayerNorm (blocks.py:137,143,149). */
 int dm_layernorm(const void* x, long ldx, void* y, long ldy, int rows, int c, int dtype,
@@ -159,6 +171,8 @@ int dm_convert(const void* src, int src_dtype, void* dst, int dst_dtype, long n,
 int dm_gather_row(const float* table, long ld, const int* index, float* dst, long ld_dst, int batch, int n,
                   hipStream_t stream);
 int dm_advance_counter(int* counter, int delta, hipStream_t stream);
+/* Zero `bytes` bytes (a memset node when captured): statistics buffers, arrival counters. */
+int dm_zero(void* ptr, long bytes, hipStream_t stream);
 
 /* hipGraph capture of a sequence of the launches above (the sampler-loop body). */
 int dm_graph_begin(hipStream_t stream);

@@ -38,7 +38,7 @@ def up(eng, x2d):
 @pytest.fixture(params=DTYPES, ids=["f32", "bf16"])
 def eng(request, dev):
     e = Engine.get(dev, request.param)
-    e.arena.reset()
+    e.reset()
     e.tile_override = None
     return e
 
@@ -139,6 +139,37 @@ def test_gemm_streamk_geglu_and_conv(eng, blocks):
             assert max_rel(eng.rows_to_nchw(out, bsz, cout, ho, wo), ref) < tol(eng.dtype), (cin, cout, stride, upx, tile)
     eng.tile_override = None
     assert int(eng.ws_sk[:4096].max()) == 0
+
+
+@pytest.mark.parametrize("tile,sk", [(_lib.TILE_D128x128_S2, 1), (_lib.TILE_D256x128_S3, -100), (_lib.TILE_D64x64_S2, -37),
+                                     (_lib.TILE_D128x64_S2, 1), (_lib.TILE_64x64, 1), (_lib.TILE_D32x64_S4, -9)])
+def test_gemm_fused_groupnorm_statistics(eng, tile, sk):
+    """The GEMM accumulates per-channel sums of what it stores; GroupNorm then needs no statistics pass.
+    Two producers fill the two channel slices of one buffer (the skip-concat case)."""
+    b, hw, k, n1, n2 = 3, 64, 640, 320, 160
+    m = b * hw
+    a = tin("fs.a", (m, k)); w1 = tin("fs.w1", (n1, k), scale=1 / math.sqrt(k)); w2 = tin("fs.w2", (n2, k), scale=1 / math.sqrt(k))
+    b1 = tin("fs.b1", (n1,)) + 0.5; b2 = tin("fs.b2", (n2,)) - 1.0
+    gamma = tin("fs.g", (n1 + n2,)) + 1; beta = tin("fs.be", (n1 + n2,))
+    lins = []
+    for w, bb in ((w1, b1), (w2, b2)):
+        lin = torch.nn.Linear(k, w.shape[0])
+        with torch.no_grad():
+            lin.weight.copy_(w); lin.bias.copy_(bb)
+        lins.append(eng.pack_linear(lin))
+    buf = eng.new(m, n1 + n2)
+    eng.gn_register(buf, b)
+    eng.tile_override = (tile, sk)
+    ad = up(eng, a)
+    eng.gemm(ad, lins[0], out=buf[:, :n1], gn_batch=b)
+    eng.gemm(ad, lins[1], out=buf[:, n1:], gn_batch=b)
+    eng.tile_override = None
+    assert eng._gn_lookup(buf, b) is not None, "statistics were not fused"
+    out = eng.groupnorm(buf, b, hw, gamma.to(eng.device), beta.to(eng.device), 1e-5, True)
+    y = torch.cat([rnd(a, eng.dtype) @ rnd(w1, eng.dtype).t() + b1, rnd(a, eng.dtype) @ rnd(w2, eng.dtype).t() + b2], 1)
+    y = rnd(y, eng.dtype).reshape(b, hw, n1 + n2).permute(0, 2, 1)
+    ref = F.silu(F.group_norm(y, 32, gamma, beta, eps=1e-5)).permute(0, 2, 1).reshape(m, n1 + n2)
+    assert max_rel(out.float(), ref) < (2e-5 if eng.dtype == torch.float32 else 2e-2)
 
 
 def test_gemm_geglu(eng):

@@ -27,6 +27,7 @@ ap.add_argument("--arms", nargs="+", default=["streamk=0", "streamk=1"])
 ap.add_argument("--rounds", type=int, default=2)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--keep-tuned", action="store_true", help="tune once per arm and reuse on later visits")
+ap.add_argument("--share-tuned", action="store_true", help="tune once, with the first arm, and reuse for every arm")
 args = ap.parse_args()
 
 cfg = dict(bench.CONFIGS[args.config])
@@ -47,6 +48,8 @@ def apply(arm):
         k, v = kv.split("=")
         if k == "streamk":
             Engine._TUNE_STREAMK = STREAMK if int(v) else ()
+        elif k == "legacy":
+            Engine._TUNE_LEGACY_SK = bool(int(v))
         elif k == "gn_blocks":
             eng.gn_blocks = int(v)
         else:
@@ -56,7 +59,9 @@ def apply(arm):
 for r in range(args.rounds):
     for arm in args.arms:
         apply(arm)
-        if args.keep_tuned and arm in saved:
+        if args.share_tuned and saved:
+            eng.tuned = next(iter(saved.values()))
+        elif args.keep_tuned and arm in saved:
             eng.tuned = saved[arm]
         else:
             eng.tuned = {}
