@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdm_hip.so")
 
 DM_F32, DM_BF16 = 0, 1
-EPI_PLAIN, EPI_GEGLU, EPI_NCHW_F32 = 0, 1, 2
+EPI_PLAIN, EPI_GEGLU, EPI_NCHW_F32, EPI_QUICKGELU = 0, 1, 2, 3
 TILE_AUTO, TILE_128x128, TILE_64x128, TILE_64x64, TILE_256x128, TILE_32x64 = 0, 1, 2, 3, 4, 5
 (TILE_D128x128_S2, TILE_D128x128_S3, TILE_D256x128_S3, TILE_D64x128_S3, TILE_D64x128_S4, TILE_D64x64_S4,
  TILE_D32x64_S4, TILE_D256x64_S3, TILE_D128x64_S4) = range(11, 20)
@@ -66,7 +66,8 @@ _PROTOS = {
     "dm_groupnorm_stats": (C.c_int, [_vp, _l, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "dm_groupnorm_apply": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp]),
     "dm_layernorm": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _f, _vp]),
-    "dm_attention": (C.c_int, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _vp]),
+    "dm_attention": (C.c_int, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dm_embed_tokens": (C.c_int, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp]),
     "dm_transpose_v": (C.c_int, [_vp, _l, _i, _i, _i, _i, _vp, _l, _i, _vp]),
     "dm_linear_rows": (C.c_int, [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "dm_timestep_embedding": (C.c_int, [_vp, _i, _i, _f, _vp, _vp]),
@@ -106,7 +107,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dm_abi_version() != 1:
+        if handle.dm_abi_version() != 2:
             raise RuntimeError("libdm_hip.so ABI version mismatch; rebuild with `python build.py`")
         _lib = handle
     return _lib

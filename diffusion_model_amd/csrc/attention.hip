@@ -37,6 +37,7 @@ struct AttnArgs {
     const char* vt; long ldv;
     char* o; long ldo;
     int heads, sq, sk;
+    int causal;        // 1: key j is visible to query i only when j <= i (attention.py:35-37)
     int nqblk, nblk;   // query blocks per (batch, head); blocks in the grid
     float scale_log2;  // log2(e) / sqrt(d)
 };
@@ -223,6 +224,16 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                     for (int r = 0; r < 4; ++r)
                         if (t * KT + key_of(kt, 4 * qp + r) >= p.sk) sacc[kt][qt][r] = -INFINITY;
             }
+            // causal: keys after the query position are masked (wave-uniform test: does this tile reach
+            // past the wave's first query row at all?)
+            if (p.causal && (t + 1) * KT > q0 + qt * 16 + 1) {
+                const int qrow = q0 + qt * 16 + c;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (t * KT + key_of(kt, 4 * qp + r) > qrow) sacc[kt][qt][r] = -INFINITY;
+            }
             float mloc = sacc[0][qt][0];
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
@@ -398,8 +409,10 @@ template <typename T> int attn_dispatch(const AttnArgs& a, int batch, int d, hip
 }  // namespace
 
 extern "C" int dm_attention(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldv, void* o,
-                            long ldo, int batch, int heads, int sq, int sk, int d, int dtype, hipStream_t stream) {
+                            long ldo, int batch, int heads, int sq, int sk, int d, int causal, int dtype,
+                            hipStream_t stream) {
     if (!q || !k || !vt || !o || batch <= 0 || heads <= 0 || sq <= 0 || sk <= 0) return DM_ERR_ARG;
+    if (causal && sq != sk) return DM_ERR_ARG;
     if (dtype != DM_F32 && dtype != DM_BF16) return DM_ERR_ARG;
     const int epc = dtype == DM_F32 ? 4 : 8;
     if (ldv % 64 || ldv < sk || ldv < ((sk + 8 * epc - 1) / (8 * epc)) * 8 * epc) return DM_ERR_ARG;
@@ -411,6 +424,7 @@ extern "C" int dm_attention(const void* q, long ldq, const void* k, long ldk, co
     a.vt = static_cast<const char*>(vt); a.ldv = ldv;
     a.o = static_cast<char*>(o); a.ldo = ldo;
     a.heads = heads; a.sq = sq; a.sk = sk;
+    a.causal = causal ? 1 : 0;
     a.scale_log2 = 1.4426950408889634f / sqrtf((float)d);
     return dtype == DM_F32 ? attn_dispatch<float>(a, batch, d, stream) : attn_dispatch<bf16_t>(a, batch, d, stream);
 }

@@ -188,6 +188,27 @@ __global__ __launch_bounds__(EW_THREADS) void gather_row_kernel(const float* __r
     }
 }
 
+// out[(b, s)][:] = table[token[b][s]][:] + pos[s][:], stored in the engine dtype (fp32 or bf16).
+// The sum is formed in fp32 from the fp32 tables, as nn.Embedding + the broadcast add do.
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void embed_tokens_kernel(const long long* __restrict__ tokens,
+                                                                   const float* __restrict__ table,
+                                                                   const float* __restrict__ pos, T* __restrict__ out,
+                                                                   long ld, int rows, int seq, int dim, int vocab) {
+    const int dim4 = dim >> 2;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)rows * dim4;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / dim4), j = (int)(idx - (long)row * dim4) << 2;
+        long long tok = tokens[row];
+        tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);  // the host rejects out-of-range ids; never fault here
+        const f32x4 e = *reinterpret_cast<const f32x4*>(table + tok * dim + j);
+        const f32x4 q = *reinterpret_cast<const f32x4*>(pos + (long)(row % seq) * dim + j);
+        T* dst = out + (long)row * ld + j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ElemTraits<T>::store(dst + r, e[r] + q[r]);
+    }
+}
+
 // Single-lane vector load/store; every other launch on the stream is ordered after it.
 __global__ void advance_counter_kernel(int* counter, int delta) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -305,6 +326,23 @@ extern "C" int dm_gather_row(const float* table, long ld, const int* index, floa
     if (!table || !index || !dst || batch <= 0 || n <= 0) return DM_ERR_ARG;
     hipLaunchKernelGGL(gather_row_kernel, dim3(ew_blocks((long)batch * n)), dim3(EW_THREADS), 0, stream, table, ld, index,
                        dst, ld_dst, batch, n);
+    return dm_check_launch();
+}
+
+extern "C" int dm_embed_tokens(const long long* tokens, const float* table, const float* pos, void* out, long ld,
+                               int rows, int seq, int dim, int vocab, int dtype, hipStream_t stream) {
+    if (!tokens || !table || !pos || !out || rows <= 0 || seq <= 0 || dim <= 0 || dim % 4 || vocab <= 0 || ld < dim)
+        return DM_ERR_ARG;
+    if (!dm_aligned16(table) || !dm_aligned16(pos)) return DM_ERR_ALIGN;
+    const dim3 grid(ew_blocks((long)rows * (dim / 4))), block(EW_THREADS);
+    if (dtype == DM_F32)
+        hipLaunchKernelGGL(embed_tokens_kernel<float>, grid, block, 0, stream, tokens, table, pos,
+                           static_cast<float*>(out), ld, rows, seq, dim, vocab);
+    else if (dtype == DM_BF16)
+        hipLaunchKernelGGL(embed_tokens_kernel<bf16_t>, grid, block, 0, stream, tokens, table, pos,
+                           static_cast<bf16_t*>(out), ld, rows, seq, dim, vocab);
+    else
+        return DM_ERR_ARG;
     return dm_check_launch();
 }
 

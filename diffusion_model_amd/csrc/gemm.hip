@@ -261,6 +261,14 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FM][4],
                     }
                 }
             }
+            if (p.epi == DM_EPI_QUICKGELU) {
+                // x * sigmoid(1.702 x)  (src/models/clip.py:114)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if constexpr (sizeof(T) == 4) o[q] = o[q] * (1.0f / (1.0f + __expf(-1.702f * o[q])));
+                    else o[q] = o[q] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554670f * o[q]));
+                }
+            }
             if (p.stats) {
                 // keep the value as stored (after rounding) in the accumulator for the statistics pass below
 #pragma unroll
@@ -919,7 +927,9 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     } else if (d->k % epc) {
         return DM_ERR_ARG;
     }
+    if (d->epi < DM_EPI_PLAIN || d->epi > DM_EPI_QUICKGELU) return DM_ERR_ARG;
     if (d->epi == DM_EPI_GEGLU && (!d->bias || d->n % 64 || d->rowbias || d->r)) return DM_ERR_ARG;
+    if (d->epi == DM_EPI_QUICKGELU && d->r) return DM_ERR_ARG;  // activation of a sum with a residual is not a thing here
     if ((d->rowbias || d->epi == DM_EPI_NCHW_F32 || d->stats) && d->rows_per_batch <= 0) return DM_ERR_ARG;
     if (d->stats && (d->epi != DM_EPI_PLAIN || (reinterpret_cast<uintptr_t>(d->stats) & 7u) || d->ld_stats < d->n))
         return DM_ERR_ARG;

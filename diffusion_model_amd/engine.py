@@ -223,7 +223,7 @@ class Engine:
     def gemm(self, a: torch.Tensor, pw: PackedWeight, out: Optional[torch.Tensor] = None, *, bias=True,
              rowbias: Optional[torch.Tensor] = None, rows_per_batch: int = 0, residual: Optional[torch.Tensor] = None,
              conv: Optional[dict] = None, nchw_out: Optional[torch.Tensor] = None, persistent=False,
-             gn_batch: int = 0) -> torch.Tensor:
+             gn_batch: int = 0, act: Optional[str] = None) -> torch.Tensor:
         """``gn_batch`` > 0: a GroupNorm over ``gn_batch`` samples reads the output next; its statistics are
         accumulated by this launch where the chosen tile allows it."""
         d = GemmDesc()
@@ -248,6 +248,10 @@ class Engine:
                 out = self.new(m, n_out, persistent=persistent)
             d.c, d.ldc = out.data_ptr(), out.stride(0)
             d.epi = _lib.EPI_GEGLU if pw.geglu else _lib.EPI_PLAIN
+            if act is not None:
+                if act != "quickgelu" or pw.geglu or residual is not None:
+                    raise RuntimeError(f"unsupported fused activation {act!r}")
+                d.epi = _lib.EPI_QUICKGELU
         d.a, d.lda = a.data_ptr(), a.stride(0)
         d.w = pw.w.data_ptr()
         d.bias = pw.bias.data_ptr() if (bias and pw.bias is not None) else None
@@ -415,13 +419,25 @@ class Engine:
                                           self.stream), "transpose_v")
         return vt
 
-    def attention(self, q, k, vt, batch, heads, sq, sk, d, out=None) -> torch.Tensor:
+    def attention(self, q, k, vt, batch, heads, sq, sk, d, out=None, causal=False) -> torch.Tensor:
         if out is None:
             out = self.new(batch * sq, heads * d)
         with self._prof("attention", 4.0 * batch * heads * sq * sk * d, f"b={batch} sq={sq} sk={sk} d={d}"):
             check(self.lib.dm_attention(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), vt.data_ptr(),
-                                        vt.stride(0), out.data_ptr(), out.stride(0), batch, heads, sq, sk, d, self.dm,
-                                        self.stream), "attention")
+                                        vt.stride(0), out.data_ptr(), out.stride(0), batch, heads, sq, sk, d,
+                                        int(causal), self.dm, self.stream), "attention")
+        return out
+
+    def embed_tokens(self, tokens: torch.Tensor, table: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+        """tokens (B, S) int64, table fp32 (V, E), pos fp32 (S, E) -> engine-dtype rows [B*S, E]."""
+        b, s = tokens.shape
+        v, e = table.shape
+        if pos.shape != (s, e):
+            raise RuntimeError(f"sequence of {s} tokens does not match the {tuple(pos.shape)} position table")
+        out = self.new(b * s, e)
+        tok = tokens.to(device=self.device, dtype=torch.long).contiguous()
+        check(self.lib.dm_embed_tokens(tok.data_ptr(), table.data_ptr(), pos.data_ptr(), out.data_ptr(), out.stride(0),
+                                       b * s, s, e, v, self.dm, self.stream), "embed_tokens")
         return out
 
     def linear_rows(self, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], silu_in: bool,

@@ -17,15 +17,12 @@ class SelfAttention(nn.Module):
         self.d_head = d_embed // n_heads
 
     def forward(self, x, causal_mask=False):
-        if causal_mask:
-            raise NotImplementedError(
-                "causal masking is only used by the CLIP text encoder, which is outside the denoising path")
         eng = engine_for(self, x)
         pk = rt.cached_pack(self, eng, rt.pack_self_attention)
         b, s, c = x.shape
         eng.reset()
         rows = eng.to_rows(x)
-        out = rt.run_self_attention(eng, pk, rows, b, s)
+        out = rt.run_self_attention(eng, pk, rows, b, s, causal=bool(causal_mask))
         return eng.from_rows(out, (b, s, c)).to(x.dtype)
 
 

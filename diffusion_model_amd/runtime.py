@@ -8,6 +8,7 @@ issue the kernel launches.  Mapping to the reference's forward passes:
   run_attention_block <- AttentionBlock.forward  (src/models/blocks.py:114-159)
   run_unet            <- UNet.forward            (src/models/unet.py:148-175)
   diffusion_forward   <- Diffusion.forward       (src/models/diffusion.py:73-101)
+  run_clip            <- CLIP.forward            (src/models/clip.py:167-194), CLIPLayer.forward (:91-119)
 """
 from __future__ import annotations
 
@@ -180,11 +181,11 @@ def context_kv(eng: Engine, ca: NS, ctx_rows, batch: int, sk: int, persistent=Fa
     return k, vt
 
 
-def run_self_attention(eng: Engine, sa: NS, x, batch: int, s: int, out=None, residual=None):
+def run_self_attention(eng: Engine, sa: NS, x, batch: int, s: int, out=None, residual=None, causal=False):
     c = sa.heads * sa.d
     qkv = eng.gemm(x, sa.in_proj)
     vt = eng.transpose_v(qkv[:, 2 * c:3 * c], batch, s, sa.heads, sa.d)
-    o = eng.attention(qkv[:, 0:c], qkv[:, c:2 * c], vt, batch, sa.heads, s, s, sa.d)
+    o = eng.attention(qkv[:, 0:c], qkv[:, c:2 * c], vt, batch, sa.heads, s, s, sa.d, causal=causal)
     return eng.gemm(o, sa.out_proj, out=out, residual=residual)
 
 
@@ -330,3 +331,40 @@ def diffusion_forward_into(eng: Engine, pk: NS, latent_f32: torch.Tensor, time_f
     eng.gemm(a, pk.final.conv, nchw_out=eps_out, rows_per_batch=hw,
              conv=dict(batch=batch, hin=h, win=w, hout=h, wout=w, cin_real=pk.final.cin))
     return eps_out
+
+
+# ----------------------------------------------------------------------------------------------
+# CLIP text encoder (producer of the cross-attention context)
+# ----------------------------------------------------------------------------------------------
+def pack_clip_layer(m, eng: Engine) -> NS:
+    return NS(ln1_w=_f32(eng, m.layernorm_1.weight), ln1_b=_f32(eng, m.layernorm_1.bias), ln1_eps=m.layernorm_1.eps,
+              sa=pack_self_attention(m.attention, eng),
+              ln2_w=_f32(eng, m.layernorm_2.weight), ln2_b=_f32(eng, m.layernorm_2.bias), ln2_eps=m.layernorm_2.eps,
+              fc1=eng.pack_linear(m.linear_1), fc2=eng.pack_linear(m.linear_2))
+
+
+def pack_clip(m, eng: Engine) -> NS:
+    return NS(table=_f32(eng, m.embedding.token_embedding.weight), pos=_f32(eng, m.embedding.position_embedding),
+              layers=[pack_clip_layer(l, eng) for l in m.layers],
+              ln_w=_f32(eng, m.layernorm.weight), ln_b=_f32(eng, m.layernorm.bias), ln_eps=m.layernorm.eps)
+
+
+def run_clip_layer(eng: Engine, pk: NS, x, batch: int, s: int):
+    """Pre-LN transformer layer: x + attn(LN(x)) with the causal mask, then + fc2(quickgelu(fc1(LN(.))))."""
+    mark = eng.arena.mark()
+    a = eng.layernorm(x, pk.ln1_w, pk.ln1_b, pk.ln1_eps)
+    t = run_self_attention(eng, pk.sa, a, batch, s, residual=x, causal=True)
+    a = eng.layernorm(t, pk.ln2_w, pk.ln2_b, pk.ln2_eps)
+    a = eng.gemm(a, pk.fc1, act="quickgelu")
+    eng.gemm(a, pk.fc2, out=x, residual=t)  # x is dead by now: reuse it for the layer output
+    eng.arena.release(mark)
+    return x
+
+
+def run_clip(eng: Engine, pk: NS, tokens: torch.Tensor):
+    """tokens (B, S) int64 -> engine-dtype rows [B*S, E] (embedding, layers, final LayerNorm)."""
+    batch, s = tokens.shape
+    x = eng.embed_tokens(tokens, pk.table, pk.pos)
+    for lp in pk.layers:
+        x = run_clip_layer(eng, lp, x, batch, s)
+    return eng.layernorm(x, pk.ln_w, pk.ln_b, pk.ln_eps)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 1
+#define DM_ABI_VERSION 2
 
 #define DM_F32 0
 #define DM_BF16 1
@@ -30,6 +30,7 @@ extern "C" {
 #define DM_EPI_PLAIN 0    /* C = acc (+bias) (+rowbias[batch]) (+R) */
 #define DM_EPI_GEGLU 1    /* C[m][n] = (acc_v + b_v) * gelu_erf(acc_g + b_g), N counts both halves */
 #define DM_EPI_NCHW_F32 2 /* plain epilogue, stored as fp32 (B, N, H*W) */
+#define DM_EPI_QUICKGELU 3 /* plain epilogue, then x * sigmoid(1.702 x) (src/models/clip.py:114) */
 
 #define DM_TILE_AUTO 0
 #define DM_TILE_128x128 1
@@ -123,11 +124,12 @@ int dm_layernorm(const void* x, long ldx, void* y, long ldy, int rows, int c, in
                  const float* gamma, const float* beta, float eps, hipStream_t stream);
 
 /* softmax(q k^T / sqrt(d)) v for all heads, never materialising the score matrix.
- * Replaces attention.py:34-43 (self) and attention.py:71-77 (cross).
+ * Replaces attention.py:34-43 (self; causal != 0 adds the upper-triangular mask of attention.py:35-37,
+ * used by the CLIP text encoder, and needs sq == sk) and attention.py:71-77 (cross).
  * q rows = (b, sq) at q + (b*sq + s)*ldq + h*d; k likewise with sk; vt is V transposed per head:
  * vt[((b*heads + h)*d + j)*ldv + key], zero for key in [sk, ldv), ldv a multiple of 64. */
 int dm_attention(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldv, void* o, long ldo,
-                 int batch, int heads, int sq, int sk, int d, int dtype, hipStream_t stream);
+                 int batch, int heads, int sq, int sk, int d, int causal, int dtype, hipStream_t stream);
 /* src rows (b, s), columns h*d + j  ->  vt as above (pad keys zero-filled). */
 int dm_transpose_v(const void* src, long ld, int batch, int s, int heads, int d, void* vt, long ldv, int dtype,
                    hipStream_t stream);
@@ -160,6 +162,12 @@ int dm_scale_add(const float* x, const float* y, float* out, int batch, long per
 /* out = alpha*x + beta*y (+ gamma*z), fp32 scalars from the host (K-sampler steps, CFG combine). */
 int dm_axpbypcz(const float* x, float alpha, const float* y, float beta, const float* z, float gamma, float* out,
                 long n, hipStream_t stream);
+
+/* out[(b, s)][:] = table[tokens[b][s]][:] + pos[s][:] in the engine dtype.  Replaces CLIPEmbedding.forward
+ * (src/models/clip.py:52-57): nn.Embedding lookup + learned positional add.  tokens: int64 [rows],
+ * rows = batch*seq; table fp32 [vocab][dim]; pos fp32 [seq][dim]. */
+int dm_embed_tokens(const long long* tokens, const float* table, const float* pos, void* out, long ld, int rows,
+                    int seq, int dim, int vocab, int dtype, hipStream_t stream);
 
 /* Layout / dtype plumbing around the model boundary (fp32 NCHW outside, [rows][C] inside). */
 int dm_nchw_to_rows(const float* src, int batch, int c, int hw, void* dst, long ld, int cpad, int dtype,
