@@ -73,7 +73,7 @@ def test_null_arguments_are_rejected_without_a_device():
     handle = _lib.lib()
     assert handle.dm_gemm(None, None) == 1
     assert handle.dm_ddpm_step(None, None, None, None, 16, None, None, 1, None) == 1
-    assert handle.dm_attention(None, 0, None, 0, None, 0, None, 0, 1, 8, 64, 64, 40, 0, None) == 1
+    assert handle.dm_attention(None, 0, None, 0, None, 0, None, 0, 1, 8, 64, 64, 40, 0, 0, None) == 1
     assert handle.dm_groupnorm_stats(None, 0, 1, 64, 320, 32, 0, None, 1, None) == 1
 
 
