@@ -68,7 +68,6 @@ _PROTOS = {
     "dm_layernorm": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _f, _vp]),
     "dm_attention": (C.c_int, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dm_embed_tokens": (C.c_int, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp]),
-    "dm_transpose_v": (C.c_int, [_vp, _l, _i, _i, _i, _i, _vp, _l, _i, _vp]),
     "dm_linear_rows": (C.c_int, [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "dm_timestep_embedding": (C.c_int, [_vp, _i, _i, _f, _vp, _vp]),
     "dm_ddpm_step": (C.c_int, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp]),

@@ -3,28 +3,29 @@
 //
 // Work split: block = 4 waves = 64*QT query rows of one (batch, head); each wave owns QT tiles of
 // 16 query rows and keeps their (pre-scaled) Q fragments and the running (max, sum, O) in registers.
-// K and V^T tiles (128 bytes of keys: 64 bf16 / 32 fp32) are streamed global -> LDS by
-// global_load_lds_dwordx4 into a two-stage ring: tile t+1 is in flight while tile t is consumed,
-// one barrier per tile.  Because that DMA writes LDS lane-linearly, both tile images are
-// contiguous and their bank swizzles are applied to the per-lane SOURCE address:
-//   K   image [k-step][key][64 B], 16-byte chunk c of a row stored at c ^ ksw(key)
-//   V^T image [d][128 B],          16-byte chunk c of a row stored at c ^ ((d >> 1) & 7)
+// K and V tiles (64 bf16 / 32 fp32 keys) are streamed global -> LDS by global_load_lds_dwordx4 into a
+// two-stage ring: tile t+1 is in flight while tile t is consumed, one barrier per tile.  That DMA
+// writes LDS lane-linearly, so both tile images are contiguous and any permutation is applied to the
+// per-lane SOURCE address:
+//   K image [k-step][key][64 B], 16-byte chunk c of a row stored at c ^ ksw(key)
+//   V image [key][VCH chunks]: the row's D values, then (head dims that leave spare rows in the last
+//           16-row tile of O^T) a chunk of ones, then zero chunks up to the pitch
 // Rows / keys outside the problem read a 16-byte zero buffer.
 // A 128-bit LDS read is served in four cycles, and the lanes sharing a cycle are NOT 16 consecutive
 // ones: measured on MI355X they are {0-3, 12-15, 20-23, 24-27}, {4-7, 8-11, 16-19, 28-31} and the same
-// two sets + 32.  With lane = 16*chunk + row, ksw() is chosen so that those sets hit 16 distinct
-// 16-byte slots of the 256-byte bank line: (key >> 1) & 3 for fp32 (rows = consecutive keys) and
-// (-(key >> 3)) & 3 for the permuted bf16 rows described below.
+// two sets + 32.  With lane = 16*chunk + row, ksw() = (key >> 1) & 3 makes those sets hit 16 distinct
+// 16-byte slots of the 256-byte bank line.
 //
 // The score tile is computed transposed, S^T = K Q^T (K is the MFMA row operand), so that after the
 // MFMA every lane holds scores of ONE query row (column l&15) for keys 4*(l>>4)+r: the row max/sum
 // need only two cross-lane steps, and the probabilities are already laid out as the column
-// operand of the second product O^T = V^T P^T, whose row operand comes from the V^T tile (keys
-// contiguous).  V^T is produced once per projection by dm_transpose_v.
-// For bf16 the 16 rows of score block kt are NOT keys 16*kt..16*kt+15: row 4*q + r of block kt is key
-// 32*(kt>>1) + 8*q + 4*(kt&1) + r, so that a lane's results from blocks 2j and 2j+1 are 8 consecutive
-// keys, i.e. exactly one 16-byte chunk of a V^T row (one ds_read_b128 per MFMA operand).
+// operand of the second product O^T = V^T P^T.  Its row operand V^T[d][8 keys] is read straight out
+// of the row-major V tile: bf16 by ds_read_b64_tr_b16 (a 4-key x 16-column block per 16 lanes,
+// delivered column-major), fp32 by one ds_read_b32 per key (the f32 MFMA takes one value per lane);
+// the fp32 row pitch is an odd number of chunks so that the four key rows read together fall in
+// different banks.  No transposed copy of V is ever made.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "dm_hip.h"
@@ -34,7 +35,7 @@ namespace {
 struct AttnArgs {
     const char* q; long ldq;
     const char* k; long ldk;
-    const char* vt; long ldv;
+    const char* v; long ldv;
     char* o; long ldo;
     int heads, sq, sk;
     int causal;        // 1: key j is visible to query i only when j <= i (attention.py:35-37)
@@ -51,6 +52,23 @@ __device__ __attribute__((aligned(16))) uint32_t g_attn_ones_f32[4] = {0x3F80000
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),          \
                                      (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Two transposed LDS reads (4 keys x 16 columns each, delivered column-major) at immediate offsets from
+// one address register.  Written as asm so that the compiler does not order them behind the LDS-DMA of the
+// NEXT tile (it drains vmcnt before an LDS read it knows about while such a DMA is in flight); the caller
+// waits with lgkmcnt(0) before using the results.
+template <int OFF0, int OFF1> __device__ __forceinline__ void tr_read_pair(u32x2& a, u32x2& b, uint32_t lds_addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                 : "=&v"(a), "=&v"(b)
+                 : "v"(lds_addr), "i"(OFF0), "i"(OFF1));
+}
+
 template <typename T, int D, int QT>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     constexpr int EPC = ElemTraits<T>::EPC;
@@ -62,16 +80,22 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     constexpr int NKT = KT / 16;
     constexpr int K_SLAB = KT * 64;            // bytes of one k-step slab
     constexpr int K_BYTES = NKS * K_SLAB;
-    constexpr int V_BYTES = DT * 16 * 128;
-    constexpr int STAGE = K_BYTES + V_BYTES;
+    constexpr int VREAL = D / EPC;             // 16-byte chunks of real values per V row
+    constexpr int VCH0 = DT * 16 / EPC;        // chunks covering every column an O^T tile touches
+    // pitch: fp32 an odd number of chunks; bf16 an odd multiple of two chunks (the eight key rows that one
+    // 32-lane half reads transposed then start in eight different 32-byte bank groups)
+    constexpr int VCH = ESZ == 4 ? (VCH0 | 1) : VCH0 + (6 - VCH0 % 4) % 4;
+    constexpr int VPITCH = VCH * 16;
+    constexpr int V_BYTES = KT * VPITCH;
     constexpr int K_PIECES = K_BYTES / 1024;   // 1 KiB = one wave-instruction of the DMA
-    constexpr int V_PIECES = V_BYTES / 1024;
+    constexpr int V_PIECES = (V_BYTES + 1023) / 1024;
+    constexpr int STAGE = K_BYTES + V_PIECES * 1024;
     constexpr int KP = (K_PIECES + 3) / 4;     // pieces per wave (upper bound)
     constexpr int VP = (V_PIECES + 3) / 4;
-    // When D leaves spare rows in the last 16-row tile of V^T, row D is fed with ones so that the
-    // second product also delivers sum_k P[q][k] (in O^T row D) and the VALU never adds the row sum.
+    // When D leaves spare rows in the last 16-row tile of O^T, column D of the V tile is fed with ones so
+    // that the second product also delivers sum_k P[q][k] (in O^T row D) and the VALU never adds the row sum.
     constexpr bool ONES = (D % 16) != 0;
-    auto ksw = [](int row) { return ESZ == 2 ? (-(row >> 3)) & 3 : (row >> 1) & 3; };
+    auto ksw = [](int row) { return (row >> 1) & 3; };
     static_assert(D % EPC == 0, "head dim must be a whole number of 16-byte chunks");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -94,8 +118,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     // ---- loader coordinates (fixed over the key loop)
     long k_off[KP];   // byte offset of this lane's 16 B inside K for tile 0
     int k_row[KP];    // key row inside the tile (validity against sk), -1 = never valid
-    const char* v_src[VP];  // this lane's 16 B of V^T for tile 0 (or the constant zero / ones buffer)
-    int v_adv[VP];          // bytes to advance per tile (0 for the constant buffers)
+    const char* v_src[VP];  // this lane's 16 B of V for tile 0 (or the constant zero / ones buffer)
+    long v_adv[VP];         // bytes to advance per tile
+    int v_key[VP];          // key row inside the tile (validity against sk), -1 = constant source
 #pragma unroll
     for (int j = 0; j < KP; ++j) {
         const int pc = wave + 4 * j;
@@ -107,15 +132,19 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
     for (int j = 0; j < VP; ++j) {
         const int pc = wave + 4 * j;
-        const int row = pc * 8 + (lane >> 3);
-        const int ch = (lane & 7) ^ ((row >> 1) & 7);
+        const int slot = pc * 64 + lane;  // 16-byte slot of the V image
+        const int key = slot / VCH, ch = slot - key * VCH;
         v_src[j] = zsrc;
         v_adv[j] = 0;
-        if (pc < V_PIECES && row < D) {
-            v_src[j] = p.vt + ((((long)b * p.heads + h) * D + row) * p.ldv + ch * EPC) * ESZ;
-            v_adv[j] = KT * ESZ;
-        } else if (ONES && row == D) {
-            v_src[j] = reinterpret_cast<const char*>(ESZ == 2 ? g_attn_ones_bf16 : g_attn_ones_f32);
+        v_key[j] = -1;
+        if (pc < V_PIECES && key < KT) {
+            if (ch < VREAL) {
+                v_src[j] = p.v + (((long)b * p.sk + key) * p.ldv + (long)h * D + ch * EPC) * ESZ;
+                v_adv[j] = (long)KT * p.ldv * ESZ;
+                v_key[j] = key;
+            } else if (ONES && ch == VREAL) {
+                v_src[j] = reinterpret_cast<const char*>(ESZ == 2 ? g_attn_ones_bf16 : g_attn_ones_f32);
+            }
         }
     }
     auto issue = [&](int t, int stage) {
@@ -134,15 +163,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         for (int j = 0; j < VP; ++j) {
             const int pc = wave + 4 * j;
             if (pc < V_PIECES) {
-                DM_GLDS16(v_src[j] + (long)t * v_adv[j], sv_ + pc * 1024);
+                const bool gone = v_key[j] >= 0 && t * KT + v_key[j] >= p.sk;  // key row past the end
+                DM_GLDS16(gone ? zsrc : v_src[j] + (long)t * v_adv[j], sv_ + pc * 1024);
             }
         }
     };
 
     // key (inside the tile) that row i of score block kt stands for
-    auto key_of = [](int kt, int i) {
-        return ESZ == 2 ? 32 * (kt >> 1) + 8 * (i >> 2) + 4 * (kt & 1) + (i & 3) : 16 * kt + i;
-    };
+    auto key_of = [](int kt, int i) { return 16 * kt + i; };
 
     const int ntiles = (p.sk + KT - 1) / KT;
     issue(0, 0);
@@ -214,26 +242,26 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                 for (int qt = 0; qt < QT; ++qt) Mma16<T>::mma(sacc[kt][qt], kf[ks & 1][kt], qf[qt][ks]);
         }
         // ---- softmax numerators; lane holds keys t*KT + key_of(kt, 4*qp + r) of query row c
+        // Masks, only on the tiles that need them (wave-uniform test): keys past the end of the sequence
+        // and, when causal, keys after the query position.  The key index is made opaque inside the branch
+        // so that none of this arithmetic is hoisted into the common path.
         const bool tail = (t + 1) * KT > p.sk;
+        if (tail || (p.causal && (t + 1) * KT > q0 + 1)) {
+            int kbase = t * KT + 4 * qp;
+            asm volatile("" : "+v"(kbase));
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                int limit = p.sk;
+                if (p.causal) limit = min(limit, q0 + qt * 16 + c + 1);
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kbase + 16 * kt + r >= limit) sacc[kt][qt][r] = -INFINITY;
+            }
+        }
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            if (tail) {
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (t * KT + key_of(kt, 4 * qp + r) >= p.sk) sacc[kt][qt][r] = -INFINITY;
-            }
-            // causal: keys after the query position are masked (wave-uniform test: does this tile reach
-            // past the wave's first query row at all?)
-            if (p.causal && (t + 1) * KT > q0 + qt * 16 + 1) {
-                const int qrow = q0 + qt * 16 + c;
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (t * KT + key_of(kt, 4 * qp + r) > qrow) sacc[kt][qt][r] = -INFINITY;
-            }
             float mloc = sacc[0][qt][0];
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
@@ -268,8 +296,18 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         }
         // ---- O^T += V^T P^T
         if constexpr (sizeof(T) == 2) {
-#pragma unroll
-            for (int kk = 0; kk < NKT / 2; ++kk) {
+            // The lane's eight probabilities of k-step kk are keys kk*32 + 4*qp + r (score block 2*kk) and
+            // kk*32 + 16 + 4*qp + r (block 2*kk + 1); V^T[d = dt*16 + c] for the same keys comes from two
+            // transposed reads: lane 4*q + pp of a 16-lane group addresses key row q, columns 4*pp .. 4*pp+3.
+            const uint32_t v_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)s_v) +
+                                    (4 * qp + (c >> 2)) * VPITCH + 8 * (c & 3);
+            static_for<0, NKT / 2>([&](auto kk_) {
+                constexpr int kk = decltype(kk_)::value;
+                u32x2 vlo[DT], vhi[DT];
+                static_for<0, DT>([&](auto dt_) {
+                    constexpr int dt = decltype(dt_)::value;
+                    tr_read_pair<kk * 32 * VPITCH + dt * 32, (kk * 32 + 16) * VPITCH + dt * 32>(vlo[dt], vhi[dt], v_addr);
+                });
                 u32x4 pb[QT];
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
@@ -277,24 +315,25 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                     pb[qt] = u32x4{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(d2[0], d2[1]),
                                    pack_bf16x2(d2[2], d2[3])};
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    // keys kk*32 + 8*qp .. +7: chunk kk*4 + qp of the row
-                    const int row = dt * 16 + c;
-                    const u32x4 va = *reinterpret_cast<const u32x4*>(
-                        s_v + row * 128 + (((kk * 4 + qp) ^ ((row >> 1) & 7)) << 4));
+                    const u32x4 va = u32x4{vlo[dt][0], vlo[dt][1], vhi[dt][0], vhi[dt][1]};
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) Mma16<T>::mma(oacc[dt][qt], va, pb[qt]);
                 }
-            }
+            });
         } else {
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const int row = dt * 16 + c;
-                    const u32x4 va = *reinterpret_cast<const u32x4*>(
-                        s_v + row * 128 + (((kt * 4 + qp) ^ ((row >> 1) & 7)) << 4));
+                    // keys 16*kt + 4*qp + e, e = 0..3, of column dt*16 + c: the e-th f32 MFMA of the chunk
+                    u32x4 va;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        va[e] = *reinterpret_cast<const uint32_t*>(s_v + (16 * kt + 4 * qp + e) * VPITCH + (dt * 16 + c) * 4);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) {
                         const f32x4 pr = sacc[kt][qt];
@@ -337,33 +376,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     }
 }
 
-// V [rows (b, s)][h*d + j] -> V^T [b][h][j][ldv]; keys in [s, ldv) are written as zero.
-template <typename T>
-__global__ __launch_bounds__(256) void transpose_v_kernel(const T* __restrict__ src, long ld, int s, int heads, int d,
-                                                          T* __restrict__ vt, long ldv) {
-    extern __shared__ __attribute__((aligned(16))) char smem_t[];
-    T* tile = reinterpret_cast<T*>(smem_t);  // [64][d + 1]
-    const int k0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-    const int tid = threadIdx.x;
-    const int stride = d + 1;
-    for (int idx = tid; idx < 64 * d; idx += 256) {
-        const int r = idx / d, j = idx - r * d;
-        const int key = k0 + r;
-        T v = 0;
-        if (key < s) v = src[((long)b * s + key) * ld + (long)h * d + j];
-        tile[r * stride + j] = v;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 64 * d; idx += 256) {
-        const int j = idx >> 6, r = idx & 63;
-        vt[(((long)b * heads + h) * d + j) * ldv + k0 + r] = tile[r * stride + j];
-    }
-}
-
 template <typename T, int D, int QT> int attn_launch_qt(const AttnArgs& a, int batch, hipStream_t s) {
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int NKS = (D * (int)sizeof(T) + 63) / 64, DT = (D + 15) / 16, KT = 8 * EPC;
-    constexpr int LDS = 2 * (NKS * KT * 64 + DT * 16 * 128);
+    constexpr int VCH0 = DT * 16 / EPC;  // V image: see the kernel
+    constexpr int VCH = sizeof(T) == 4 ? (VCH0 | 1) : VCH0 + (6 - VCH0 % 4) % 4;
+    constexpr int LDS = 2 * (NKS * KT * 64 + (KT * VCH * 16 + 1023) / 1024 * 1024);
     static bool attr_done = false;
     auto kfn = attn_kernel<T, D, QT>;
     if (!attr_done) {
@@ -408,38 +426,22 @@ template <typename T> int attn_dispatch(const AttnArgs& a, int batch, int d, hip
 
 }  // namespace
 
-extern "C" int dm_attention(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldv, void* o,
+extern "C" int dm_attention(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o,
                             long ldo, int batch, int heads, int sq, int sk, int d, int causal, int dtype,
                             hipStream_t stream) {
-    if (!q || !k || !vt || !o || batch <= 0 || heads <= 0 || sq <= 0 || sk <= 0) return DM_ERR_ARG;
+    if (!q || !k || !v || !o || batch <= 0 || heads <= 0 || sq <= 0 || sk <= 0) return DM_ERR_ARG;
     if (causal && sq != sk) return DM_ERR_ARG;
     if (dtype != DM_F32 && dtype != DM_BF16) return DM_ERR_ARG;
     const int epc = dtype == DM_F32 ? 4 : 8;
-    if (ldv % 64 || ldv < sk || ldv < ((sk + 8 * epc - 1) / (8 * epc)) * 8 * epc) return DM_ERR_ARG;
-    if (ldq % epc || ldk % epc || ldo % 4 || d % epc) return DM_ERR_ALIGN;
-    if (!dm_aligned16(q) || !dm_aligned16(k) || !dm_aligned16(vt) || !dm_aligned16(o)) return DM_ERR_ALIGN;
+    if (ldq % epc || ldk % epc || ldv % epc || ldo % 4 || d % epc) return DM_ERR_ALIGN;
+    if (!dm_aligned16(q) || !dm_aligned16(k) || !dm_aligned16(v) || !dm_aligned16(o)) return DM_ERR_ALIGN;
     AttnArgs a;
     a.q = static_cast<const char*>(q); a.ldq = ldq;
     a.k = static_cast<const char*>(k); a.ldk = ldk;
-    a.vt = static_cast<const char*>(vt); a.ldv = ldv;
+    a.v = static_cast<const char*>(v); a.ldv = ldv;
     a.o = static_cast<char*>(o); a.ldo = ldo;
     a.heads = heads; a.sq = sq; a.sk = sk;
     a.causal = causal ? 1 : 0;
     a.scale_log2 = 1.4426950408889634f / sqrtf((float)d);
     return dtype == DM_F32 ? attn_dispatch<float>(a, batch, d, stream) : attn_dispatch<bf16_t>(a, batch, d, stream);
-}
-
-extern "C" int dm_transpose_v(const void* src, long ld, int batch, int s, int heads, int d, void* vt, long ldv,
-                              int dtype, hipStream_t stream) {
-    if (!src || !vt || batch <= 0 || s <= 0 || heads <= 0 || d <= 0 || ldv % 64 || ldv < s) return DM_ERR_ARG;
-    dim3 grid((int)(ldv / 64), heads, batch);
-    if (dtype == DM_F32)
-        hipLaunchKernelGGL(transpose_v_kernel<float>, grid, dim3(256), 64 * (d + 1) * 4, stream,
-                           static_cast<const float*>(src), ld, s, heads, d, static_cast<float*>(vt), ldv);
-    else if (dtype == DM_BF16)
-        hipLaunchKernelGGL(transpose_v_kernel<bf16_t>, grid, dim3(256), 64 * (d + 1) * 2, stream,
-                           static_cast<const bf16_t*>(src), ld, s, heads, d, static_cast<bf16_t*>(vt), ldv);
-    else
-        return DM_ERR_ARG;
-    return dm_check_launch();
 }

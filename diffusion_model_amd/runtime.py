@@ -171,21 +171,19 @@ def run_residual_block(eng: Engine, pk: NS, x, batch: int, h: int, w: int, tproj
 
 
 def context_kv(eng: Engine, ca: NS, ctx_rows, batch: int, sk: int, persistent=False, out=None):
-    """K rows and per-head transposed V of the conditioning sequence for one cross-attention.
+    """K and V rows of the conditioning sequence for one cross-attention.
 
-    ``out`` = (k, vt) buffers from an earlier call to refill in place (addresses baked into a captured graph).
+    ``out`` = (k, v) buffers from an earlier call to refill in place (addresses baked into a captured graph).
     """
     k = eng.gemm(ctx_rows, ca.k_proj, out=None if out is None else out[0], persistent=persistent)
-    v = eng.gemm(ctx_rows, ca.v_proj)
-    vt = eng.transpose_v(v, batch, sk, ca.heads, ca.d, persistent=persistent, out=None if out is None else out[1])
-    return k, vt
+    v = eng.gemm(ctx_rows, ca.v_proj, out=None if out is None else out[1], persistent=persistent)
+    return k, v
 
 
 def run_self_attention(eng: Engine, sa: NS, x, batch: int, s: int, out=None, residual=None, causal=False):
     c = sa.heads * sa.d
     qkv = eng.gemm(x, sa.in_proj)
-    vt = eng.transpose_v(qkv[:, 2 * c:3 * c], batch, s, sa.heads, sa.d)
-    o = eng.attention(qkv[:, 0:c], qkv[:, c:2 * c], vt, batch, sa.heads, s, s, sa.d, causal=causal)
+    o = eng.attention(qkv[:, 0:c], qkv[:, c:2 * c], qkv[:, 2 * c:3 * c], batch, sa.heads, s, s, sa.d, causal=causal)
     return eng.gemm(o, sa.out_proj, out=out, residual=residual)
 
 
@@ -297,7 +295,7 @@ def run_unet(eng: Engine, pk: NS, x, batch: int, h: int, w: int, tproj, kvs, sk:
 
 
 def precompute_context(eng: Engine, pk_unet: NS, context: torch.Tensor, persistent=False, out=None):
-    """Cross-attention K / V^T of every AttentionBlock for a fixed conditioning tensor (B, S, 768).
+    """Cross-attention K / V of every AttentionBlock for a fixed conditioning tensor (B, S, 768).
 
     These 32 projections do not depend on the latent or the timestep, so a sampling loop computes
     them once (``persistent=True`` keeps them outside the per-forward arena; ``out`` refills the

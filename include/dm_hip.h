@@ -126,13 +126,10 @@ int dm_layernorm(const void* x, long ldx, void* y, long ldy, int rows, int c, in
 /* softmax(q k^T / sqrt(d)) v for all heads, never materialising the score matrix.
  * Replaces attention.py:34-43 (self; causal != 0 adds the upper-triangular mask of attention.py:35-37,
  * used by the CLIP text encoder, and needs sq == sk) and attention.py:71-77 (cross).
- * q rows = (b, sq) at q + (b*sq + s)*ldq + h*d; k likewise with sk; vt is V transposed per head:
- * vt[((b*heads + h)*d + j)*ldv + key], zero for key in [sk, ldv), ldv a multiple of 64. */
-int dm_attention(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldv, void* o, long ldo,
+ * q rows = (b, sq) at q + (b*sq + s)*ldq + h*d; k and v likewise with sk rows per sample (their
+ * own leading dimensions).  V is read row-major as the projection wrote it; no transposed copy. */
+int dm_attention(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
                  int batch, int heads, int sq, int sk, int d, int causal, int dtype, hipStream_t stream);
-/* src rows (b, s), columns h*d + j  ->  vt as above (pad keys zero-filled). */
-int dm_transpose_v(const void* src, long ld, int batch, int s, int heads, int d, void* vt, long ldv, int dtype,
-                   hipStream_t stream);
 
 /* y[b][n] = sum_k f(x[b][k]) * w[n][k] + bias[n], fp32, f = SiLU when silu_in.  Replaces the
  * batch-sized Linears of the time path (src/models/embeddings.py:42-44; blocks.py:63-64). */

@@ -48,6 +48,8 @@ def apply(arm):
         k, v = kv.split("=")
         if k == "streamk":
             Engine._TUNE_STREAMK = STREAMK if int(v) else ()
+        elif k == "graphtune":
+            eng._tune_graph = bool(int(v))
         elif k == "legacy":
             Engine._TUNE_LEGACY_SK = bool(int(v))
         elif k == "gn_blocks":
@@ -56,6 +58,9 @@ def apply(arm):
             setattr(eng, k, int(v))
 
 
+side = torch.cuda.Stream(dev)  # hipGraph capture (used by the tuner's timing) is not allowed on the default stream
+side.wait_stream(torch.cuda.current_stream(dev))
+torch.cuda.set_stream(side)
 for r in range(args.rounds):
     for arm in args.arms:
         apply(arm)

@@ -34,7 +34,7 @@ for sq, sk, d in SHAPES:
     q = torch.randn(B * sq, heads * d, device=dev, generator=gen).to(dt)
     k = torch.randn(B * sk, heads * d, device=dev, generator=gen).to(dt)
     v = torch.randn(B * sk, heads * d, device=dev, generator=gen).to(dt)
-    vt = eng.transpose_v(v, B, sk, heads, d, persistent=True)
+    vt = v
     out = torch.empty(B * sq, heads * d, device=dev, dtype=dt)
     eng.attention(q, k, vt, B, heads, sq, sk, d, out=out)
     torch.cuda.synchronize()
