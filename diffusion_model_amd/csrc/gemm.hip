@@ -569,14 +569,21 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
     }
 }
 
-// Two entry kernels over the same body so that profiles tell the dense GEMMs (Linear / conv1x1) from
-// the implicit-GEMM 3x3 convolutions, and so that neither carries the other's addressing code.
+// Waves per SIMD that the LDS ring lets a CU hold (capped at 4): the register budget the compiler must
+// respect, so that a rarely taken path (the partial-tile sum) can never cost the main loop its occupancy.
+constexpr int dma_min_waves(int bm, int bn, int waves, int stages) {
+    const int blocks = 163840 / (stages * (bm + bn) * 128);
+    const int w = (blocks < 8 ? blocks : 8) * waves / 4;
+    return w < 1 ? 1 : (w > 4 ? 4 : w);
+}
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_dma_kernel(GemmArgs p) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_M* WAVES_N, STAGES)) void gemm_dma_kernel(
+    GemmArgs p) {
     gemm_dma_body<T, BM, BN, WAVES_M, WAVES_N, STAGES, false>(p);
 }
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_igemm_kernel(GemmArgs p) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_M* WAVES_N, STAGES)) void conv3x3_igemm_kernel(
+    GemmArgs p) {
     gemm_dma_body<T, BM, BN, WAVES_M, WAVES_N, STAGES, true>(p);
 }
 
