@@ -365,11 +365,12 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
     constexpr int W_IT = BN * 8 / NT;
     constexpr int LOADS = A_IT + W_IT;           // LDS-DMA instructions per thread per k-tile
     constexpr int STAGE_BYTES = (BM + BN) * 128;
-    static_assert((STAGES - 2) * LOADS <= 63, "vmcnt field overflow");
+    static_assert(STAGES >= 2 && STAGES <= 4 && (STAGES - 2) * LOADS <= 63, "ring depth / vmcnt field");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS destinations become SALU arithmetic
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
     const int nkt = p.Kpad / BK;
@@ -421,51 +422,70 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
 
         ARows<A_IT> rows;
         init_rows<A_IT, NT / 8>(rows, p, m0, tid >> 3, BM);
+        // Running source pointers, advanced after every k-tile.  A row (or, in a convolution, a tap of a
+        // row) that must read as zero points at the 16-byte zero buffer with step 0, so the steady state
+        // costs one 64-bit add per DMA and no select.
         const char* w_ptr[W_IT];
 #pragma unroll
         for (int it = 0; it < W_IT; ++it)
-            w_ptr[it] = p.W + ((long)(n0 + it * (NT / 8) + (tid >> 3)) * p.Kpad + lchunk * EPC) * sizeof(T);
+            w_ptr[it] = p.W + ((long)(n0 + it * (NT / 8) + (tid >> 3)) * p.Kpad + (long)kt0 * BK + lchunk * EPC) * sizeof(T);
         int kc = kt0 * BK + lchunk * EPC, tap = 0;
         if (CONV) {
             tap = kc / p.Cin;
             kc -= tap * p.Cin;
         }
-
-        // Fast conv path (Cin a multiple of the k-tile): the tap is the same for every thread of a k-tile
-        // and changes only every Cin/BK tiles, so the per-row source offsets are recomputed only then.
-        const bool conv_fast = CONV && (p.Cin % BK == 0);
-        long cur[A_IT];
-        bool cur_ok[A_IT];
-        int c0 = 0;  // channel offset of the current k-tile inside its tap
-        if (conv_fast) {
-            c0 = kc - lchunk * EPC;
+        // Fast paths: convolution with Cin a multiple of the k-tile (the tap is the same for every thread of
+        // a k-tile and changes only every Cin/BK tiles); dense with no padded k tail.
+        const bool fast = CONV ? (p.Cin % BK == 0) : (p.Kpad == p.K);
+        const char* a_ptr[A_IT];
+        int a_step[A_IT];
+        int c0 = 0;  // channel offset of the next k-tile inside its tap
+        auto set_tap = [&]() {
 #pragma unroll
-            for (int it = 0; it < A_IT; ++it) cur_ok[it] = conv_src<A_IT>(rows, p, it, tap, lchunk * EPC, cur[it]);
+            for (int it = 0; it < A_IT; ++it) {
+                long e;
+                const bool ok = conv_src<A_IT>(rows, p, it, tap, lchunk * EPC, e);
+                a_ptr[it] = ok ? p.A + (e + c0) * sizeof(T) : zsrc;
+                a_step[it] = ok ? BK * (int)sizeof(T) : 0;
+            }
+        };
+        if (fast) {
+            if (CONV) {
+                c0 = kc - lchunk * EPC;
+                set_tap();
+            } else {
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) {
+                    a_ptr[it] = rows.ok[it] ? p.A + (rows.off[it] + (long)kt0 * BK + lchunk * EPC) * sizeof(T) : zsrc;
+                    a_step[it] = rows.ok[it] ? BK * (int)sizeof(T) : 0;
+                }
+            }
         }
 
+        // one k-tile of DMAs; called for kt < kt1 only
         auto issue = [&](int kt, int stage) {
             char* sa = smem + stage * STAGE_BYTES + lds_wave;
             char* sw = sa + BM * 128;
-            const bool live = kt < kt1;
-            if (conv_fast) {
+            if (fast) {
 #pragma unroll
                 for (int it = 0; it < A_IT; ++it) {
-                    const char* src = (cur_ok[it] && live) ? p.A + (cur[it] + c0) * sizeof(T) : zsrc;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_ptr[it],
                                                      (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
+                    a_ptr[it] += a_step[it];
                 }
-                c0 += BK;
-                if (c0 == p.Cin) {
-                    c0 = 0;
-                    ++tap;
-#pragma unroll
-                    for (int it = 0; it < A_IT; ++it) cur_ok[it] = conv_src<A_IT>(rows, p, it, tap, lchunk * EPC, cur[it]);
+                if (CONV) {
+                    c0 += BK;
+                    if (c0 == p.Cin) {
+                        c0 = 0;
+                        ++tap;
+                        set_tap();
+                    }
                 }
             } else if (CONV) {
 #pragma unroll
                 for (int it = 0; it < A_IT; ++it) {
                     long e;
-                    const bool ok = conv_src<A_IT>(rows, p, it, tap, kc, e) && live;
+                    const bool ok = conv_src<A_IT>(rows, p, it, tap, kc, e);
                     const char* src = ok ? p.A + e * sizeof(T) : zsrc;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                      (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
@@ -479,7 +499,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
                 const int k = kt * BK + lchunk * EPC;
 #pragma unroll
                 for (int it = 0; it < A_IT; ++it) {
-                    const bool ok = rows.ok[it] && k < p.K && live;
+                    const bool ok = rows.ok[it] && k < p.K;
                     const char* src = ok ? p.A + (rows.off[it] + k) * sizeof(T) : zsrc;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                      (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
@@ -487,9 +507,9 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
             }
 #pragma unroll
             for (int it = 0; it < W_IT; ++it) {
-                const char* src = live ? w_ptr[it] + (long)kt * BK * sizeof(T) : zsrc;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[it],
                                                  (__attribute__((address_space(3))) void*)(sw + it * (NT * 16)), 16, 0, 0);
+                w_ptr[it] += BK * sizeof(T);
             }
         };
 
@@ -499,20 +519,28 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        // prologue: tiles kt0 .. kt0+STAGES-2 in flight (out-of-range tiles are issued as zero loads so
-        // that every wave's vmcnt arithmetic stays uniform)
+        // prologue: up to STAGES-1 tiles in flight
 #pragma unroll
-        for (int s = 0; s < STAGES - 1; ++s) issue(kt0 + s, s);
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (kt0 + s < kt1) issue(kt0 + s, s);
 
         int stage = 0;
         for (int kt = kt0; kt < kt1; ++kt) {
-            // tile kt has landed once at most (STAGES-2) younger tiles are outstanding; the barrier makes
-            // every wave's share visible and retires all reads of the stage refilled below
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LOADS) : "memory");
+            // tile kt has landed once only the younger tiles in flight (at most STAGES-2, fewer at the end
+            // of the run) are outstanding; the barrier makes every wave's share visible and retires all
+            // reads of the stage refilled below
+            if constexpr (STAGES == 2) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                const int young = kt1 - 1 - kt;
+                if (STAGES >= 4 && young >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+                else if (young >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
             int nstage = stage + STAGES - 1;
             if (nstage >= STAGES) nstage -= STAGES;
-            issue(kt + STAGES - 1, nstage);
+            if (kt + STAGES - 1 < kt1) issue(kt + STAGES - 1, nstage);
             const char* sa = smem + stage * STAGE_BYTES;
             mma_tile<T, FM>(acc, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq);
             if (++stage == STAGES) stage = 0;
