@@ -121,6 +121,27 @@ __device__ __forceinline__ bool conv_src(const ARows<A_IT>& r, const GemmArgs& p
 template <typename T, int FM>
 __device__ __forceinline__ void mma_tile(f32x4 (&acc)[FM][4], const char* sa, const char* sw, int arow0, int wrow0, int fr,
                                          int fq) {
+    if constexpr (sizeof(T) == 2 && FM == 4) {
+        // bf16: every fragment of the k-tile is requested before the first MFMA, so that only the first
+        // k-step's LDS latency is exposed; the second k-step's reads land behind the first one's MFMAs
+        // (LDS returns in order, so the waits in between are counted ones).
+        u32x4 af[2][FM], wf[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[ks][j] = *reinterpret_cast<const u32x4*>(sw + swz(wrow0 + j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < FM; ++i) af[ks][i] = *reinterpret_cast<const u32x4*>(sa + swz(arow0 + i * 16 + fr, ks * 4 + fq));
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs (the scheduler would sink them)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma16<T>::mma(acc[i][j], wf[ks][j], af[ks][i]);
+        return;
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         u32x4 af[FM], wf[4];
