@@ -315,14 +315,23 @@ def precompute_context(eng: Engine, pk_unet: NS, context: torch.Tensor, persiste
     return kvs, sk
 
 
-def diffusion_forward_into(eng: Engine, pk: NS, latent_f32: torch.Tensor, time_f32: torch.Tensor, kvs, sk: int,
-                           eps_out: torch.Tensor):
-    """Launch-only body (no torch allocation): latent (B,4,H,W) fp32, time (B,320) fp32 -> eps_out (B,4,H,W) fp32."""
-    batch, cin, h, w = latent_f32.shape
-    hw = h * w
+def time_projections(eng: Engine, pk: NS, time_f32: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """(rows, 320) timestep features -> (rows, sum of C_out) fp32: TimeEmbedding followed by every ResidualBlock's
+    ``linear_time(silu(.))``, all blocks side by side.  Rows are independent, so a sampling loop whose batch shares
+    one timestep per step computes the table for all its steps once instead of three launches per step."""
     t = eng.linear_rows(time_f32, pk.te.w1, pk.te.b1, silu_in=False)
     t = eng.linear_rows(t, pk.te.w2, pk.te.b2, silu_in=True)
-    tproj = eng.linear_rows(t, pk.unet.lt_w, pk.unet.lt_b, silu_in=True)
+    return eng.linear_rows(t, pk.unet.lt_w, pk.unet.lt_b, silu_in=True, out=out)
+
+
+def diffusion_forward_into(eng: Engine, pk: NS, latent_f32: torch.Tensor, time_f32: Optional[torch.Tensor], kvs, sk: int,
+                           eps_out: torch.Tensor, tproj: Optional[torch.Tensor] = None):
+    """Launch-only body (no torch allocation): latent (B,4,H,W) fp32, time (B,320) fp32 -> eps_out (B,4,H,W) fp32.
+    ``tproj`` (B, sum of C_out; row stride 0 allowed) replaces the time path when the caller already has it."""
+    batch, cin, h, w = latent_f32.shape
+    hw = h * w
+    if tproj is None:
+        tproj = time_projections(eng, pk, time_f32)
     x = eng.nchw_to_rows(latent_f32, cpad=_rup(cin, 8))
     x, ho, wo = run_unet(eng, pk.unet, x, batch, h, w, tproj, kvs, sk)
     a = eng.groupnorm(x, batch, hw, pk.final.gn_w, pk.final.gn_b, pk.final.gn_eps, silu=True)

@@ -159,6 +159,8 @@ class _DdpmLoop:
         self.stream = torch.cuda.Stream(device)
         self.kvs = None
         self.sk = sk
+        self.tproj_table = None  # [T][sum of ResidualBlock C_out] time projections of every step, loop order
+        self.tproj_row = None
         self.graph = C.c_void_p()
 
     def __del__(self):
@@ -171,10 +173,14 @@ class _DdpmLoop:
     def _body(self):
         s = self.eng.stream
         B = self.shape[0]
-        check(self.lib.dm_gather_row(self.temb.data_ptr(), 320, self.counter.data_ptr(), self.time_in.data_ptr(), 320,
-                                     B, 320, s), "gather_row")
+        # every sample of the batch is at the same timestep: one row of the per-step table of time projections
+        # (computed once per sampling call) serves the whole batch through a zero row stride
+        n = self.tproj_table.shape[1]
+        check(self.lib.dm_gather_row(self.tproj_table.data_ptr(), n, self.counter.data_ptr(), self.tproj_row.data_ptr(),
+                                     n, 1, n, s), "gather_row")
         self.eng.reset()
-        rt.diffusion_forward_into(self.eng, self.pk, self.x, self.time_in, self.kvs, self.sk, self.eps)
+        rt.diffusion_forward_into(self.eng, self.pk, self.x, None, self.kvs, self.sk, self.eps,
+                                  tproj=self.tproj_row.expand(B, n))
         check(self.lib.dm_ddpm_step(self.x.data_ptr(), self.eps.data_ptr(), self.noise.data_ptr(), self.x.data_ptr(),
                                     self.x.numel(), self.coef.data_ptr(), self.counter.data_ptr(), self.clip, s),
               "ddpm_step")
@@ -195,6 +201,11 @@ class _DdpmLoop:
                 self.noise[i].copy_(nz)
             self.counter.zero_()
             self.eng.reset()
+            if self.tproj_table is None:
+                n = self.pk.unet.lt_w.shape[0]
+                self.tproj_table = torch.empty(self.T, n, dtype=torch.float32, device=self.device)
+                self.tproj_row = torch.empty(1, n, dtype=torch.float32, device=self.device)
+            rt.time_projections(self.eng, self.pk, self.temb, out=self.tproj_table)
             self.kvs, _ = rt.precompute_context(self.eng, self.pk.unet, context, persistent=self.kvs is None,
                                                 out=self.kvs)
             done = 0
