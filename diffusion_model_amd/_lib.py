@@ -49,6 +49,7 @@ class GemmDesc(C.Structure):
         ("splitk", C.c_int),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_long),
         ("stats", C.c_void_p), ("ld_stats", C.c_long),
+        ("ln_in", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_out", C.c_void_p),
     ]
 
 

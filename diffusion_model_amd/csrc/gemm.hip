@@ -47,6 +47,10 @@ struct GemmArgs {
     int epi;
     int splitk;
     float* partial;
+    const double* ln_in;     // per-row (sum, sumsq) of A: the LayerNorm that precedes this GEMM is folded in
+    const float* ln_colsum;  // sum over k of each packed weight row (packed order)
+    float ln_eps;
+    double* ln_out;          // per-row (sum, sumsq) of the stored output, atomically accumulated
     double* stats;  // per-channel (sum, sumsq) of the stored output, [batch][2][ld_stats], atomically accumulated
     long ld_stats;
     int streamk;    // stream-K: number of blocks sharing the (tile, k-tile) work list; 0 = one tile per block
@@ -169,12 +173,38 @@ __device__ __forceinline__ void mma_tile(f32x4 (&acc)[FM][4], const char* sa, co
     }
 }
 
+// mean and 1/sqrt(var + eps) of the rows this lane will finish, from the per-row (sum, sumsq) that the producer
+// of A accumulated.  The difference of the two moments is taken in fp64 (cancellation), the rest in fp32.
+template <int FM>
+__device__ __forceinline__ void ln_row_stats(const GemmArgs& p, int mrow0, int ngroup0, int fr, int fq, float (&mu)[FM],
+                                             float (&rs)[FM], f32x4 (&cs)[4]) {
+    const float inv_k = 1.0f / (float)p.K;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        cs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.ln_in) cs[j] = *reinterpret_cast<const f32x4*>(p.ln_colsum + ngroup0 + 16 * j + 4 * fq);
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = mrow0 + i * 16 + fr;
+        mu[i] = 0.f;
+        rs[i] = 0.f;
+        if (p.ln_in && m < p.M) {
+            const double mean = p.ln_in[2L * m] * (double)inv_k;
+            const float var = fmaxf((float)(p.ln_in[2L * m + 1] * (double)inv_k - mean * mean), 0.f);
+            mu[i] = (float)mean;
+            rs[i] = rsqrtf(var + p.ln_eps);
+        }
+    }
+}
+
 // Epilogue: lane holds, for row m = mrow0 + 16*i + fr, columns ncol0 + 4*j + r (16 consecutive).
 // Column-only terms (bias) are fetched once per lane, outside the row loop; bf16 rows are written as
 // 16-byte pieces.
 template <typename T, int FM>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FM][4], int mrow0, int ngroup0, int fr, int fq,
-                                         int kslice) {
+                                         int kslice, const float (&ln_mu)[FM], const float (&ln_rs)[FM],
+                                         const f32x4 (&ln_cs)[4]) {
     const int ncol0 = ngroup0 + fq * 16;
     if (p.splitk > 1) {
 #pragma unroll
@@ -189,6 +219,17 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FM][4],
             }
         }
         return;
+    }
+    if (p.ln_in) {
+        // A was the raw input of a LayerNorm whose scale is folded into W and whose shift is folded into the
+        // bias: LN(a) W^T = rstd * (a W'^T - mean * colsum(W')) + (beta W^T + b).  mean / rstd of this lane's
+        // rows were fetched before the main loop (ln_row_stats), so no load latency is exposed here.
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = ln_rs[i] * (acc[i][j][r] - ln_mu[i] * ln_cs[j][r]);
     }
     if (p.epi == DM_EPI_GEGLU) {
         // lane holds 8 value columns nb..nb+7 (j = 0, 1) and their gates (j = 2, 3)
@@ -237,6 +278,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FM][4],
         const int m = mrow0 + i * 16 + fr;
         if (m >= p.M) continue;
         const int bidx = p.rowbias ? m / p.rows_per_batch : 0;
+        float row_s = 0.f, row_q = 0.f;  // sums of this row's stored values (for a following LayerNorm)
         // two 8-column halves; N is a multiple of 4, so a half is all-valid, half-valid or absent
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -290,6 +332,16 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FM][4],
                     else o[q] = o[q] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554670f * o[q]));
                 }
             }
+            if (p.ln_out) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q < 4 || full) {
+                        float v = o[q];
+                        if constexpr (sizeof(T) == 2) v = bf16_to_f32(f32_to_bf16(v));
+                        row_s += v;
+                        row_q = fmaf(v, v, row_q);
+                    }
+            }
             if (p.stats) {
                 // keep the value as stored (after rounding) in the accumulator for the statistics pass below
 #pragma unroll
@@ -317,6 +369,17 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FM][4],
                 } else {
                     *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
                 }
+            }
+        }
+        if (p.ln_out) {
+            // the four lanes that share this row (one per 16-column group) add up, then one of them publishes
+            row_s += __shfl_xor(row_s, 16);
+            row_q += __shfl_xor(row_q, 16);
+            row_s += __shfl_xor(row_s, 32);
+            row_q += __shfl_xor(row_q, 32);
+            if (fq == 0) {
+                atomicAdd(p.ln_out + 2L * m, (double)row_s);
+                atomicAdd(p.ln_out + 2L * m + 1, (double)row_q);
             }
         }
     }
@@ -539,6 +602,9 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float ln_mu[FM], ln_rs[FM];
+        f32x4 ln_cs[4];
+        ln_row_stats<FM>(p, m0 + wm * 16 * FM, n0 + wn * 64, fr, fq, ln_mu, ln_rs, ln_cs);
 
         // prologue: up to STAGES-1 tiles in flight
 #pragma unroll
@@ -614,7 +680,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
                     }
             }
         }
-        epilogue<T, FM>(p, acc, m0 + wm * 16 * FM, n0 + wn * 64, fr, fq, blockIdx.y);
+        epilogue<T, FM>(p, acc, m0 + wm * 16 * FM, n0 + wn * 64, fr, fq, blockIdx.y, ln_mu, ln_rs, ln_cs);
     }
 }
 
@@ -747,7 +813,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_reg_kernel(GemmArg
         if (more) store_tile(cur ^ 1);
         __syncthreads();
     }
-    epilogue<T, FM>(p, acc, m0 + wm * 16 * FM, n0 + wn * 64, fr, fq, blockIdx.y);
+    float ln_mu[FM], ln_rs[FM];
+    f32x4 ln_cs[4];
+    ln_row_stats<FM>(p, m0 + wm * 16 * FM, n0 + wn * 64, fr, fq, ln_mu, ln_rs, ln_cs);
+    epilogue<T, FM>(p, acc, m0 + wm * 16 * FM, n0 + wn * 64, fr, fq, blockIdx.y, ln_mu, ln_rs, ln_cs);
 }
 
 // Sum split-K partial slabs in slab order (deterministic) and apply the plain epilogue.
@@ -994,6 +1063,11 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     if (tile == DM_TILE_AUTO) dm_gemm_plan(d->dtype, d->m, d->n, d->k, d->epi, &tile, &splitk);
     int bm, bn;
     if (tile_dims(tile, &bm, &bn)) return DM_ERR_ARG;
+    // folded / produced LayerNorm statistics live in the epilogue: not with the separate split-K reduction
+    if ((d->ln_in || d->ln_out) && splitk > 1) return DM_ERR_ARG;
+    if (d->ln_in && (!d->ln_colsum || d->conv || !dm_aligned16(d->ln_colsum) || (reinterpret_cast<uintptr_t>(d->ln_in) & 7u)))
+        return DM_ERR_ARG;
+    if (d->ln_out && (d->epi != DM_EPI_PLAIN || (reinterpret_cast<uintptr_t>(d->ln_out) & 7u))) return DM_ERR_ARG;
     // fused statistics: a wave's rows must lie inside one sample, and the separate split-K reduction
     // launch does not produce them
     if (d->stats && (d->rows_per_batch % tile_wave_rows(tile) || d->m % d->rows_per_batch || splitk > 1)) return DM_ERR_ARG;
@@ -1034,6 +1108,10 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     a.partial = static_cast<float*>(d->workspace);
     a.stats = d->stats;
     a.ld_stats = d->ld_stats;
+    a.ln_in = d->ln_in;
+    a.ln_colsum = d->ln_colsum;
+    a.ln_eps = d->ln_eps;
+    a.ln_out = d->ln_out;
     a.streamk = streamk;
     a.counters = static_cast<int*>(d->workspace);
     a.slabs = streamk ? reinterpret_cast<float*>(static_cast<char*>(d->workspace) + streamk_counter_bytes(tile, d->m, d->n))

@@ -62,11 +62,13 @@ class Arena:
 
 class PackedWeight:
     """Weight matrix in the GEMM kernel's layout plus its fp32 bias."""
-    __slots__ = ("w", "n", "k", "npad", "kpad", "bias", "geglu", "conv_cin")
+    __slots__ = ("w", "n", "k", "npad", "kpad", "bias", "geglu", "conv_cin", "colsum", "ln_eps")
 
     def __init__(self, w, n, k, npad, kpad, bias, geglu=False, conv_cin=0):
         self.w, self.n, self.k, self.npad, self.kpad = w, n, k, npad, kpad
         self.bias, self.geglu, self.conv_cin = bias, geglu, conv_cin
+        self.colsum = None  # set when a LayerNorm is folded in: sum over k of every packed row (fp32)
+        self.ln_eps = 0.0
 
 
 class Engine:
@@ -108,6 +110,8 @@ class Engine:
         self._stats_dirty = 0  # high-water mark of elements that may be non-zero
         self._gn_shared: List[dict] = []      # buffers with several producers (skip-concat buffers)
         self._gn_auto: Dict[int, dict] = {}   # data_ptr -> record of a tensor written by one GEMM
+        self._ln_stats: Dict[int, torch.Tensor] = {}  # data_ptr -> [rows][2] fp64 row sums (folded LayerNorm)
+        self.fuse_ln = os.environ.get("DM_FUSE_LN", "1") == "1"
         self.fuse_gn_stats = os.environ.get("DM_FUSE_GN_STATS", "1") == "1"
         self.profile: Optional[dict] = None  # kernel class -> [events...] when profiling
         self._order_cache: Dict[Tuple[int, int, bool], torch.Tensor] = {}
@@ -138,6 +142,7 @@ class Engine:
         self.arena.reset()
         self._gn_shared.clear()
         self._gn_auto.clear()
+        self._ln_stats.clear()
         if self._stats_dirty:
             check(self.lib.dm_zero(self.stats_buf.data_ptr(), self._stats_dirty * 8, self.stream), "zero")
         self._stats_off = 0
@@ -205,8 +210,22 @@ class Engine:
         b = None if bias is None else bias.detach().to(device=self.device, dtype=torch.float32).contiguous()
         return PackedWeight(wp, n, k, npad, kpad, b, geglu, conv_cin)
 
-    def pack_linear(self, lin: torch.nn.Linear, geglu=False) -> PackedWeight:
-        return self.pack_matrix(lin.weight, lin.bias, geglu)
+    def pack_linear(self, lin: torch.nn.Linear, geglu=False, ln: Optional[torch.nn.LayerNorm] = None) -> PackedWeight:
+        """``ln``: the LayerNorm whose output is this Linear's only input.  Its scale goes into the weights
+        (W' = W diag(gamma)), its shift into the bias (beta W^T + b); the per-row mean / rstd are applied by the
+        GEMM epilogue from row sums that the producer of the LayerNorm's input accumulated."""
+        if ln is None:
+            return self.pack_matrix(lin.weight, lin.bias, geglu)
+        w = lin.weight.detach().to(self.device, torch.float32)
+        gamma = ln.weight.detach().to(self.device, torch.float32)
+        beta = ln.bias.detach().to(self.device, torch.float32)
+        bias = w @ beta
+        if lin.bias is not None:
+            bias = bias + lin.bias.detach().to(self.device, torch.float32)
+        pw = self.pack_matrix(w * gamma[None, :], bias, geglu)
+        pw.colsum = pw.w.float().sum(dim=1).contiguous()  # of the values the MFMA really sees (after rounding)
+        pw.ln_eps = float(ln.eps)
+        return pw
 
     def pack_conv1x1(self, conv: torch.nn.Conv2d) -> PackedWeight:
         return self.pack_matrix(conv.weight.reshape(conv.out_channels, conv.in_channels), conv.bias)
@@ -223,9 +242,13 @@ class Engine:
     def gemm(self, a: torch.Tensor, pw: PackedWeight, out: Optional[torch.Tensor] = None, *, bias=True,
              rowbias: Optional[torch.Tensor] = None, rows_per_batch: int = 0, residual: Optional[torch.Tensor] = None,
              conv: Optional[dict] = None, nchw_out: Optional[torch.Tensor] = None, persistent=False,
-             gn_batch: int = 0, act: Optional[str] = None) -> torch.Tensor:
+             gn_batch: int = 0, act: Optional[str] = None, ln_in: Optional[torch.Tensor] = None,
+             ln_out: bool = False) -> torch.Tensor:
         """``gn_batch`` > 0: a GroupNorm over ``gn_batch`` samples reads the output next; its statistics are
-        accumulated by this launch where the chosen tile allows it."""
+        accumulated by this launch where the chosen tile allows it.
+        ``ln_out``: a LayerNorm folded into a later GEMM reads the output next; per-row sums are accumulated
+        here (fetch them with ``ln_stats(out)``).  ``ln_in``: such sums for the rows of ``a``; ``pw`` must have
+        been packed with that LayerNorm (``pack_linear(..., ln=...)``)."""
         d = GemmDesc()
         if conv is not None:
             m = conv["batch"] * conv["hout"] * conv["wout"]
@@ -267,15 +290,28 @@ class Engine:
             if d.epi != _lib.EPI_PLAIN and sk.value > 1:
                 sk.value = 1
         else:
-            key = (m, pw.n, pw.k, d.conv, d.stride, d.up, d.epi, residual is not None, rowbias is not None)
+            no_legacy = ln_in is not None or ln_out
+            key = (m, pw.n, pw.k, d.conv, d.stride, d.up, d.epi, residual is not None, rowbias is not None, no_legacy)
             best = self.tuned.get(key)
             if best is None and self.autotune and not self.arena.frozen and self.profile is None:
-                best = self._tune(d, key)
+                best = self._tune(d, key, legacy=not no_legacy)
             if best is not None:
                 tile.value, sk.value = best
             else:
                 self.lib.dm_gemm_plan(self.dm, m, pw.n, pw.k, d.epi, C.byref(tile), C.byref(sk))
+        if (ln_in is not None or ln_out) and sk.value > 1:
+            sk.value = 1  # the separate split-K reduction launch does not carry the LayerNorm epilogue
         d.tile, d.splitk = tile.value, sk.value
+        if ln_in is not None:
+            if pw.colsum is None:
+                raise RuntimeError("ln_in needs weights packed with their LayerNorm")
+            d.ln_in, d.ln_colsum, d.ln_eps = ln_in.data_ptr(), pw.colsum.data_ptr(), pw.ln_eps
+        elif pw.colsum is not None:
+            raise RuntimeError("weights packed with a LayerNorm need the row statistics of their input (ln_in)")
+        if ln_out:
+            st = self._stats_alloc(m, 1).view(m, 2)
+            self._ln_stats[out.data_ptr()] = st
+            d.ln_out = st.data_ptr()
         if sk.value > 1:
             self._bind_workspace(d, m, pw.n, sk.value)
         elif sk.value < 0:
@@ -354,7 +390,11 @@ class Engine:
             e1.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    def _tune(self, d: GemmDesc, key):
+    def ln_stats(self, t: torch.Tensor) -> torch.Tensor:
+        """Row sums accumulated by the GEMM that wrote ``t`` (``ln_out=True``)."""
+        return self._ln_stats[t.data_ptr()]
+
+    def _tune(self, d: GemmDesc, key, legacy: bool = True):
         nkt = d.kpad // self.bk
         best, best_t = None, float("inf")
         for tile in self._TUNE_TILES:
@@ -363,7 +403,7 @@ class Engine:
                 continue
             blocks = ((d.m + bm - 1) // bm) * ((d.n + bn - 1) // bn)
             for sk in self._TUNE_SK:
-                if sk > 1 and not self._TUNE_LEGACY_SK:
+                if sk > 1 and not (self._TUNE_LEGACY_SK and legacy):
                     break
                 if sk > 1 and (d.epi != _lib.EPI_PLAIN or nkt // sk < 2 or blocks * sk > 8192
                                or d.m * d.n * sk * 4 > (256 << 20)):

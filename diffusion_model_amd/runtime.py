@@ -62,12 +62,13 @@ def pack_residual_block(m, eng: Engine) -> NS:
               t_off=0)
 
 
-def pack_self_attention(m, eng: Engine) -> NS:
-    return NS(heads=m.n_heads, d=m.d_head, in_proj=eng.pack_linear(m.in_proj), out_proj=eng.pack_linear(m.out_proj))
+def pack_self_attention(m, eng: Engine, ln=None) -> NS:
+    """``ln``: the LayerNorm in front of the attention (AttentionBlock only); folded into ``in_proj``."""
+    return NS(heads=m.n_heads, d=m.d_head, in_proj=eng.pack_linear(m.in_proj, ln=ln), out_proj=eng.pack_linear(m.out_proj))
 
 
-def pack_cross_attention(m, eng: Engine) -> NS:
-    return NS(heads=m.n_heads, d=m.d_head, q_proj=eng.pack_linear(m.q_proj), k_proj=eng.pack_linear(m.k_proj),
+def pack_cross_attention(m, eng: Engine, ln=None) -> NS:
+    return NS(heads=m.n_heads, d=m.d_head, q_proj=eng.pack_linear(m.q_proj, ln=ln), k_proj=eng.pack_linear(m.k_proj),
               v_proj=eng.pack_linear(m.v_proj), out_proj=eng.pack_linear(m.out_proj))
 
 
@@ -77,11 +78,12 @@ def pack_attention_block(m, eng: Engine) -> NS:
               gn_w=_f32(eng, m.group_norm.weight), gn_b=_f32(eng, m.group_norm.bias), gn_eps=m.group_norm.eps,
               conv_in=eng.pack_conv1x1(m.conv_input),
               ln1_w=_f32(eng, m.layer_norm_1.weight), ln1_b=_f32(eng, m.layer_norm_1.bias), ln1_eps=m.layer_norm_1.eps,
-              sa=pack_self_attention(m.attention_1, eng),
+              fold=eng.fuse_ln,  # LayerNorms folded into in_proj / q_proj / linear_geglu_1
+              sa=pack_self_attention(m.attention_1, eng, ln=m.layer_norm_1 if eng.fuse_ln else None),
               ln2_w=_f32(eng, m.layer_norm_2.weight), ln2_b=_f32(eng, m.layer_norm_2.bias), ln2_eps=m.layer_norm_2.eps,
-              ca=pack_cross_attention(m.attention_2, eng),
+              ca=pack_cross_attention(m.attention_2, eng, ln=m.layer_norm_2 if eng.fuse_ln else None),
               ln3_w=_f32(eng, m.layer_norm_3.weight), ln3_b=_f32(eng, m.layer_norm_3.bias), ln3_eps=m.layer_norm_3.eps,
-              geglu1=eng.pack_linear(m.linear_geglu_1, geglu=True),
+              geglu1=eng.pack_linear(m.linear_geglu_1, geglu=True, ln=m.layer_norm_3 if eng.fuse_ln else None),
               geglu2=eng.pack_linear(m.linear_geglu_2),
               conv_out=eng.pack_conv1x1(m.conv_output))
 
@@ -180,17 +182,21 @@ def context_kv(eng: Engine, ca: NS, ctx_rows, batch: int, sk: int, persistent=Fa
     return k, v
 
 
-def run_self_attention(eng: Engine, sa: NS, x, batch: int, s: int, out=None, residual=None, causal=False):
+def run_self_attention(eng: Engine, sa: NS, x, batch: int, s: int, out=None, residual=None, causal=False,
+                       ln_in=None, ln_out=False):
+    """``ln_in``: row sums of ``x`` when the LayerNorm in front is folded into ``in_proj``; ``ln_out``: accumulate
+    the row sums of the result for the LayerNorm that follows."""
     c = sa.heads * sa.d
-    qkv = eng.gemm(x, sa.in_proj)
+    qkv = eng.gemm(x, sa.in_proj, ln_in=ln_in)
     o = eng.attention(qkv[:, 0:c], qkv[:, c:2 * c], qkv[:, 2 * c:3 * c], batch, sa.heads, s, s, sa.d, causal=causal)
-    return eng.gemm(o, sa.out_proj, out=out, residual=residual)
+    return eng.gemm(o, sa.out_proj, out=out, residual=residual, ln_out=ln_out)
 
 
-def run_cross_attention(eng: Engine, ca: NS, x, kv, batch: int, s: int, sk: int, out=None, residual=None):
-    q = eng.gemm(x, ca.q_proj)
+def run_cross_attention(eng: Engine, ca: NS, x, kv, batch: int, s: int, sk: int, out=None, residual=None,
+                        ln_in=None, ln_out=False):
+    q = eng.gemm(x, ca.q_proj, ln_in=ln_in)
     o = eng.attention(q, kv[0], kv[1], batch, ca.heads, s, sk, ca.d)
-    return eng.gemm(o, ca.out_proj, out=out, residual=residual)
+    return eng.gemm(o, ca.out_proj, out=out, residual=residual, ln_out=ln_out)
 
 
 def run_attention_block(eng: Engine, pk: NS, x, batch: int, h: int, w: int, kv, sk: int, out=None):
@@ -199,13 +205,21 @@ def run_attention_block(eng: Engine, pk: NS, x, batch: int, h: int, w: int, kv, 
         out = eng.new(batch * s, pk.c)
     mark = eng.arena.mark()
     a = eng.groupnorm(x, batch, s, pk.gn_w, pk.gn_b, pk.gn_eps, silu=False)
-    t = eng.gemm(a, pk.conv_in)
-    a = eng.layernorm(t, pk.ln1_w, pk.ln1_b, pk.ln1_eps)
-    t = run_self_attention(eng, pk.sa, a, batch, s, residual=t)
-    a = eng.layernorm(t, pk.ln2_w, pk.ln2_b, pk.ln2_eps)
-    t = run_cross_attention(eng, pk.ca, a, kv, batch, s, sk, residual=t)
-    a = eng.layernorm(t, pk.ln3_w, pk.ln3_b, pk.ln3_eps)
-    a = eng.gemm(a, pk.geglu1)
+    if pk.fold:
+        # The three LayerNorms never run as kernels: each GEMM that writes the residual stream also accumulates
+        # the row sums, and the GEMM behind the LayerNorm (weights pre-scaled by gamma) applies mean / rstd.
+        t = eng.gemm(a, pk.conv_in, ln_out=True)
+        t = run_self_attention(eng, pk.sa, t, batch, s, residual=t, ln_in=eng.ln_stats(t), ln_out=True)
+        t = run_cross_attention(eng, pk.ca, t, kv, batch, s, sk, residual=t, ln_in=eng.ln_stats(t), ln_out=True)
+        a = eng.gemm(t, pk.geglu1, ln_in=eng.ln_stats(t))
+    else:
+        t = eng.gemm(a, pk.conv_in)
+        a = eng.layernorm(t, pk.ln1_w, pk.ln1_b, pk.ln1_eps)
+        t = run_self_attention(eng, pk.sa, a, batch, s, residual=t)
+        a = eng.layernorm(t, pk.ln2_w, pk.ln2_b, pk.ln2_eps)
+        t = run_cross_attention(eng, pk.ca, a, kv, batch, s, sk, residual=t)
+        a = eng.layernorm(t, pk.ln3_w, pk.ln3_b, pk.ln3_eps)
+        a = eng.gemm(a, pk.geglu1)
     t = eng.gemm(a, pk.geglu2, residual=t)
     eng.gemm(t, pk.conv_out, out=out, residual=x, gn_batch=batch)
     eng.arena.release(mark)

@@ -95,6 +95,17 @@ typedef struct DmGemmDesc {
                            * zeroes the buffer).  Needs rows_per_batch, the plain epilogue, no split-K reduction
                            * launch, and dm_gemm_stats_supported(tile, rows_per_batch, splitk) != 0. */
     long ld_stats;
+    /* LayerNorm folded into the GEMMs on either side of it (blocks.py:137-138,143-144,149-150):
+     * ln_out: the producer adds, per output row m, sum and sum of squares of the stored row to
+     *         ln_out[2m], ln_out[2m+1] (fp64 atomics; caller zeroes; plain epilogue; no split-K launch);
+     * ln_in : the consumer takes the same array for its A rows and computes
+     *         rstd_m * (a_m W'^T - mean_m * colsum(W')) + bias, where the caller has packed W' = W diag(gamma),
+     *         passes ln_colsum[p] = sum_k W'_packed[p][k] (packed row order, npad entries, fp32) and has put
+     *         beta W^T (+ b) into `bias`.  ln_eps is the LayerNorm's epsilon; the width is k. */
+    const double* ln_in;
+    const float* ln_colsum;
+    float ln_eps;
+    double* ln_out;
 } DmGemmDesc;
 
 int dm_gemm(const DmGemmDesc* d, hipStream_t stream);

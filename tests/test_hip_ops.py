@@ -172,6 +172,37 @@ def test_gemm_fused_groupnorm_statistics(eng, tile, sk):
     assert max_rel(out.float(), ref) < (2e-5 if eng.dtype == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("geglu", [False, True])
+@pytest.mark.parametrize("tile,sk", [(_lib.TILE_AUTO, 1), (_lib.TILE_D128x128_S2, -40), (_lib.TILE_D64x64_S2, 1)])
+def test_gemm_folded_layernorm(eng, geglu, tile, sk):
+    """LayerNorm between two GEMMs never runs as a kernel: the first GEMM accumulates row sums of what it stores,
+    the second (weights pre-scaled by gamma, bias + beta W^T) applies mean / rstd in its epilogue."""
+    m, k0, c = 150, 256, 320
+    n = 8 * c if geglu else 3 * c
+    a = tin("fl.a", (m, k0)); w0 = tin("fl.w0", (c, k0), scale=1 / math.sqrt(k0)); b0 = tin("fl.b0", (c,)) + 0.7
+    r = tin("fl.r", (m, c)) * 2
+    gamma = tin("fl.g", (c,)) + 1; beta = tin("fl.be", (c,))
+    w1 = tin("fl.w1", (n, c), scale=1 / math.sqrt(c)); b1 = tin("fl.b1", (n,))
+    l0 = torch.nn.Linear(k0, c); l1 = torch.nn.Linear(c, n); ln = torch.nn.LayerNorm(c, eps=1e-5)
+    with torch.no_grad():
+        l0.weight.copy_(w0); l0.bias.copy_(b0); l1.weight.copy_(w1); l1.bias.copy_(b1)
+        ln.weight.copy_(gamma); ln.bias.copy_(beta)
+    p0 = eng.pack_linear(l0); p1 = eng.pack_linear(l1, geglu=geglu, ln=ln)
+    eng.tile_override = None if tile == _lib.TILE_AUTO else (tile, sk)
+    t = eng.gemm(up(eng, a), p0, residual=up(eng, r), ln_out=True)
+    out = eng.gemm(t, p1, ln_in=eng.ln_stats(t))
+    eng.tile_override = None
+    tt = rnd(rnd(a, eng.dtype) @ rnd(w0, eng.dtype).t() + b0 + rnd(r, eng.dtype), eng.dtype)
+    assert max_rel(t.float(), tt) < tol(eng.dtype)
+    y = F.linear(F.layer_norm(tt, (c,), gamma, beta, 1e-5), w1, b1)
+    if geglu:
+        v, g = y.chunk(2, dim=-1)
+        y = v * F.gelu(g)
+    assert max_rel(out.float(), y) < (5e-5 if eng.dtype == torch.float32 else 3e-2)
+    with pytest.raises(RuntimeError):
+        eng.gemm(t, p1)  # weights packed with a LayerNorm are useless without the row statistics
+
+
 def test_gemm_geglu(eng):
     m, c = 150, 320
     a = tin("gg.a", (m, c)); w = tin("gg.w", (8 * c, c), scale=1 / math.sqrt(c)); b = tin("gg.b", (8 * c,))

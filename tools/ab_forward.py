@@ -64,6 +64,7 @@ torch.cuda.set_stream(side)
 for r in range(args.rounds):
     for arm in args.arms:
         apply(arm)
+        model.__dict__.pop("_dm_pack_cache", None)  # switches that change the weight packs (fuse_ln) take effect
         if args.share_tuned and saved:
             eng.tuned = next(iter(saved.values()))
         elif args.keep_tuned and arm in saved:
