@@ -22,7 +22,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from diffusion_model_amd.models import Diffusion  # noqa: E402
+from diffusion_model_amd.models import CLIP, Diffusion  # noqa: E402
 from diffusion_model_amd.parallel import gather_latents, init_distributed  # noqa: E402
 from diffusion_model_amd.schedulers import DDPMScheduler  # noqa: E402
 from diffusion_model_amd.schedulers.base_scheduler import sinusoidal_table  # noqa: E402
@@ -119,14 +119,26 @@ def main():
 
     B, HW, T = cfg["batch"], cfg["latent"], args.ddpm_steps
     model = build_model(device, cfg["dtype"])
-    ctx = torch.randn(B, 77, 768, generator=torch.Generator().manual_seed(1 + rank)).to(device)
+    if args.config == 3:
+        # config 3 conditions on CLIP output: random-init text encoder of the same dtype, random token ids
+        # (seed 2 + rank); the encode runs once per sampling pass, inside the timed region
+        with torch.device("meta"):
+            clip = CLIP()
+        clip = deterministic_fill_(clip.to_empty(device=device), seed=0)
+        clip = (clip.bfloat16() if cfg["dtype"] == "bf16" else clip).eval()
+        tokens = torch.randint(0, 49408, (B, 77), generator=torch.Generator().manual_seed(2 + rank)).to(device)
+        ctx = None
+    else:
+        clip, tokens = None, None
+        ctx = torch.randn(B, 77, 768, generator=torch.Generator().manual_seed(1 + rank)).to(device)
     sched = DDPMScheduler(num_train_timesteps=T, clip_sample=True)
     sched.use_hip_graph = not args.no_graph
     gen = torch.Generator(device=device).manual_seed(42 + rank)
     shape = (B, 4, HW, HW)
 
     def one_step():
-        lat = sched.sample(model, shape, ctx, gen, device)
+        context = clip(tokens).float() if clip is not None else ctx
+        lat = sched.sample(model, shape, context, gen, device)
         return gather_latents(lat) if world > 1 else lat
 
     for _ in range(args.warmup):
@@ -148,7 +160,7 @@ def main():
     assert torch.isfinite(out).all()
 
     if rank == 0:
-        prof = kernel_class_profile(model, ctx, HW, B, device)
+        prof = kernel_class_profile(model, clip(tokens).float() if clip is not None else ctx, HW, B, device)
         conv = prof["conv3x3"]
         tflops = conv["work"] / (conv["ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[cfg["dtype"]]
@@ -170,7 +182,9 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": cfg["dtype"],
-            "data": "synthetic (deterministic random-init weights, seeded context, device-generated noise)",
+            "data": "synthetic (deterministic random-init weights, "
+                    + ("CLIP context from random token ids, " if clip is not None else "seeded random context, ")
+                    + "device-generated noise)",
             "config": {"workload": cfg["name"], "batch_per_gpu": B, "global_batch": B * world,
                        "latent": f"{HW}x{HW}", "ddpm_steps": T, "hip_graph": sched.use_hip_graph,
                        "parallelism": f"dp{world}"},

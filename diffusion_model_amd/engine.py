@@ -359,7 +359,8 @@ class Engine:
     _TUNE_SK = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)
     _TUNE_STREAMK = (256, 512, 768, 1024)  # blocks sharing the (tile, k-tile) work list
     _TUNE_STREAMK_MULT = (2, 3, 4, 6, 8, 12, 16, 24)  # ... and whole multiples of the tile count
-    _TUNE_LEGACY_SK = True  # also try split-K with a separate reduction launch
+    _TUNE_LEGACY_SK = False  # split-K with a separate reduction launch: measured slower overall than the work-list
+                             # form once GroupNorm / LayerNorm statistics ride in the GEMM epilogue
 
     def _time_candidate(self, d: GemmDesc, reps: int = 6) -> Optional[float]:
         """Device time (ms) of one launch of ``d``.  The launches are captured into a hipGraph and the replay is

@@ -28,7 +28,7 @@ def load(d, counter):
 
 def klass(name):
     m = re.search(r"(conv3x3_igemm_kernel|gemm_dma_kernel|attn_kernel|gn_stats_kernel|gn_apply_kernel|layernorm_kernel|"
-                  r"splitk_reduce_kernel|transpose_v_kernel|linear_rows_kernel)", name)
+                  r"splitk_reduce_kernel|linear_rows_kernel)", name)
     return m.group(1) if m else None
 
 
