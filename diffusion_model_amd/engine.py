@@ -119,6 +119,15 @@ class Engine:
         self.autotune = os.environ.get("DM_AUTOTUNE", "0") == "1"  # the sampling loop switches it on
         self.gn_blocks = int(os.environ.get("DM_GN_BLOCKS", "1024"))  # GroupNorm statistics blocks per launch
         self.tuned: Dict[tuple, Tuple[int, int]] = {}
+        # DM_TUNE_CACHE=<file>: reuse (and extend) the tuned (tile, split) table across processes, so that a
+        # profiled run contains no tuning launches
+        self._tune_cache = os.environ.get("DM_TUNE_CACHE")
+        if self._tune_cache and os.path.exists(self._tune_cache):
+            import ast
+            import json
+            with open(self._tune_cache) as f:
+                for k, v in json.load(f).get(str(dtype), {}).items():
+                    self.tuned[ast.literal_eval(k)] = tuple(v)
 
     # ------------------------------------------------------------------ utilities
     @property
@@ -430,7 +439,21 @@ class Engine:
                     best, best_t = (tile, -grid), t
         if best is not None:
             self.tuned[key] = best
+            if self._tune_cache:
+                self._save_tuned()
         return best
+
+    def _save_tuned(self):
+        import json
+        data = {}
+        if os.path.exists(self._tune_cache):
+            with open(self._tune_cache) as f:
+                data = json.load(f)
+        data[str(self.dtype)] = {repr(k): list(v) for k, v in self.tuned.items()}
+        tmp = self._tune_cache + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump(data, f)
+        os.replace(tmp, self._tune_cache)
 
     def groupnorm(self, x: torch.Tensor, batch: int, hw: int, gamma, beta, eps: float, silu: bool,
                   out: Optional[torch.Tensor] = None, groups: int = 32) -> torch.Tensor:
