@@ -69,6 +69,8 @@ _PROTOS = {
     "dm_layernorm": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _f, _vp]),
     "dm_attention": (C.c_int, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dm_embed_tokens": (C.c_int, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp]),
+    "dm_rescale": (C.c_int, [_vp, _vp, _l, _i, _f, _f, _f, _f, _i, _f, _f, _vp]),
+    "dm_images_to_u8": (C.c_int, [_vp, _i, _i, _i, _l, _f, _f, _f, _f, _f, _f, _vp, _vp]),
     "dm_linear_rows": (C.c_int, [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "dm_timestep_embedding": (C.c_int, [_vp, _i, _i, _f, _vp, _vp]),
     "dm_ddpm_step": (C.c_int, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp]),
@@ -107,7 +109,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dm_abi_version() != 2:
+        if handle.dm_abi_version() != 3:
             raise RuntimeError("libdm_hip.so ABI version mismatch; rebuild with `python build.py`")
         _lib = handle
     return _lib

@@ -209,6 +209,68 @@ __global__ __launch_bounds__(EW_THREADS) void embed_tokens_kernel(const long lon
     }
 }
 
+// ---- image range / layout (scripts/utils.py:41-53 rescale; scripts/inference.py:337-343 uint8 chain) ----
+// t = (x - old_min) / old_span; t = t * new_span + new_min; optional clamp to [lo, hi].  Every step is a
+// separately rounded operation in the tensor's own dtype (a bf16 tensor rounds to bf16 after each one), the
+// division is a true division, so the result is bitwise what the torch expression gives.
+struct RescaleArgs {
+    float old_min, old_span, new_span, new_min, lo, hi;
+    int clamp;
+};
+template <typename T> __device__ __forceinline__ float round_as(float v) { return v; }
+template <> __device__ __forceinline__ float round_as<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+template <typename T> __device__ __forceinline__ float rescale_one(float v, const RescaleArgs& a) {
+    float t = round_as<T>(__fsub_rn(v, a.old_min));
+    t = round_as<T>(__fdiv_rn(t, a.old_span));
+    t = round_as<T>(__fmul_rn(t, a.new_span));
+    t = round_as<T>(__fadd_rn(t, a.new_min));
+    if (a.clamp) t = fminf(fmaxf(t, a.lo), a.hi);
+    return t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void rescale_kernel(const T* __restrict__ x, T* __restrict__ y, long n,
+                                                              RescaleArgs a) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        ElemTraits<T>::store(y + i, rescale_one<T>(ElemTraits<T>::load(x + i), a));
+}
+
+// (B, C, H, W) -> rescaled, clamped, truncated to uint8, stored (B, H, W, C).  One thread per pixel; a wave
+// reads 64 consecutive pixels of each channel plane and writes 64*C consecutive bytes.
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void images_to_u8_kernel(const T* __restrict__ x, int c, long hw,
+                                                                   unsigned char* __restrict__ out, RescaleArgs a) {
+    const int b = blockIdx.y;
+    const T* src = x + (long)b * c * hw;
+    unsigned char* dst = out + (long)b * c * hw;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long)gridDim.x * blockDim.x)
+        for (int ch = 0; ch < c; ++ch)
+            dst[p * c + ch] = (unsigned char)(int)rescale_one<T>(ElemTraits<T>::load(src + (long)ch * hw + p), a);
+}
+
+// Three-channel fp32 images with H*W a multiple of 4: a thread converts 4 pixels (three 16-byte loads,
+// one 12-byte store).
+__global__ __launch_bounds__(EW_THREADS) void images_to_u8_rgb4_kernel(const float* __restrict__ x, long hw,
+                                                                        unsigned char* __restrict__ out, RescaleArgs a) {
+    const int b = blockIdx.y;
+    const float* src = x + (long)b * 3 * hw;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out + (long)b * 3 * hw);
+    const long q = hw >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += (long)gridDim.x * blockDim.x) {
+        f32x4 v[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) v[ch] = reinterpret_cast<const f32x4*>(src + (long)ch * hw)[i];
+        uint32_t bytes[12];
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) bytes[px * 3 + ch] = (uint32_t)(int)rescale_one<float>(v[ch][px], a);
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+            dst[i * 3 + w] = bytes[4 * w] | (bytes[4 * w + 1] << 8) | (bytes[4 * w + 2] << 16) | (bytes[4 * w + 3] << 24);
+    }
+}
+
 // Single-lane vector load/store; every other launch on the stream is ordered after it.
 __global__ void advance_counter_kernel(int* counter, int delta) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -343,6 +405,42 @@ extern "C" int dm_embed_tokens(const long long* tokens, const float* table, cons
                            static_cast<bf16_t*>(out), ld, rows, seq, dim, vocab);
     else
         return DM_ERR_ARG;
+    return dm_check_launch();
+}
+
+extern "C" int dm_rescale(const void* x, void* y, long n, int dtype, float old_min, float old_span, float new_span,
+                          float new_min, int clamp, float lo, float hi, hipStream_t stream) {
+    if (!x || !y || n <= 0 || old_span == 0.0f) return DM_ERR_ARG;
+    const RescaleArgs a{old_min, old_span, new_span, new_min, lo, hi, clamp};
+    if (dtype == DM_F32)
+        hipLaunchKernelGGL(rescale_kernel<float>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, stream,
+                           static_cast<const float*>(x), static_cast<float*>(y), n, a);
+    else if (dtype == DM_BF16)
+        hipLaunchKernelGGL(rescale_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, stream,
+                           static_cast<const bf16_t*>(x), static_cast<bf16_t*>(y), n, a);
+    else
+        return DM_ERR_ARG;
+    return dm_check_launch();
+}
+
+extern "C" int dm_images_to_u8(const void* x, int dtype, int batch, int c, long hw, float old_min, float old_span,
+                               float new_span, float new_min, float lo, float hi, unsigned char* out,
+                               hipStream_t stream) {
+    if (!x || !out || batch <= 0 || batch > 65535 || c <= 0 || hw <= 0 || old_span == 0.0f) return DM_ERR_ARG;
+    if (!(lo >= 0.0f && hi <= 255.0f && lo <= hi)) return DM_ERR_ARG;  // the clamp is what keeps the uint8 cast defined
+    const RescaleArgs a{old_min, old_span, new_span, new_min, lo, hi, 1};
+    if (dtype == DM_F32 && c == 3 && hw % 4 == 0 && dm_aligned16(x) && (reinterpret_cast<uintptr_t>(out) & 3u) == 0) {
+        hipLaunchKernelGGL(images_to_u8_rgb4_kernel, dim3(ew_blocks(hw / 4), batch), dim3(EW_THREADS), 0, stream,
+                           static_cast<const float*>(x), hw, out, a);
+    } else if (dtype == DM_F32) {
+        hipLaunchKernelGGL(images_to_u8_kernel<float>, dim3(ew_blocks(hw), batch), dim3(EW_THREADS), 0, stream,
+                           static_cast<const float*>(x), c, hw, out, a);
+    } else if (dtype == DM_BF16) {
+        hipLaunchKernelGGL(images_to_u8_kernel<bf16_t>, dim3(ew_blocks(hw), batch), dim3(EW_THREADS), 0, stream,
+                           static_cast<const bf16_t*>(x), c, hw, out, a);
+    } else {
+        return DM_ERR_ARG;
+    }
     return dm_check_launch();
 }
 

@@ -8,12 +8,14 @@
 along the batch, so the model sees a doubled batch and the two halves are recombined as
 ``cfg_scale * (cond - uncond) + uncond``.  All per-element work runs in the HIP kernels.
 """
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 
+from . import _lib
+from ._lib import check
 from .sampling.base_sampler import BaseSampler, fused_axpbypcz
-from .schedulers.base_scheduler import draw_normal, sinusoidal_table
+from .schedulers.base_scheduler import draw_normal, require_hip, sinusoidal_table, stream_of
 
 
 def get_time_embedding(timestep: int, embedding_dim: int = 320, dtype: torch.dtype = torch.float32,
@@ -51,3 +53,65 @@ def denoise(model, sampler: BaseSampler, context: torch.Tensor, latents: torch.T
         latents = sampler.step(latents, output)
     assert latents.shape[0] == batch
     return latents
+
+
+# ---- image range / layout helpers (reference: scripts/utils.py:15-94, scripts/inference.py:337-343) ----------
+def _dm_dtype(t: torch.Tensor, what: str) -> int:
+    if t.dtype == torch.float32:
+        return _lib.DM_F32
+    if t.dtype == torch.bfloat16:
+        return _lib.DM_BF16
+    raise RuntimeError(f"{what}: dtype {t.dtype} is not supported (float32 or bfloat16)")
+
+
+def rescale(tensor: torch.Tensor, old_range: Tuple[float, float], new_range: Tuple[float, float],
+            clamp: bool = False) -> torch.Tensor:
+    """``(tensor - old_min) / (old_max - old_min) * (new_max - new_min) + new_min`` (scripts/utils.py:41-53),
+    one HIP launch, rounded step by step like the reference's tensor expression."""
+    require_hip(tensor, "rescale")
+    old_min, old_max = old_range
+    new_min, new_max = new_range
+    if old_max == old_min:
+        raise ValueError("old_range is empty")
+    x = tensor.contiguous()
+    out = torch.empty_like(x)
+    check(_lib.lib().dm_rescale(x.data_ptr(), out.data_ptr(), x.numel(), _dm_dtype(x, "rescale"), float(old_min),
+                                float(old_max - old_min), float(new_max - new_min), float(new_min), int(bool(clamp)),
+                                float(new_min), float(new_max), stream_of(x)), "rescale")
+    return out
+
+
+def move_channel(tensor: torch.Tensor, to: str = "first") -> torch.Tensor:
+    """(B,H,W,C) <-> (B,C,H,W) view (scripts/utils.py:79-94); no data moves."""
+    if to == "first":
+        if tensor.ndim == 4:
+            return tensor.permute(0, 3, 1, 2)
+        if tensor.ndim == 3:
+            return tensor.permute(2, 0, 1)
+    elif to == "last":
+        if tensor.ndim == 4:
+            return tensor.permute(0, 2, 3, 1)
+        if tensor.ndim == 3:
+            return tensor.permute(1, 2, 0)
+    else:
+        raise ValueError(f"to must be 'first' or 'last', got {to}")
+    return tensor
+
+
+def images_to_uint8(images: torch.Tensor, old_range: Tuple[float, float] = (-1, 1)) -> torch.Tensor:
+    """(B, C, H, W) images in ``old_range`` -> (B, H, W, C) uint8 on the device: the reference's
+    ``rescale(images, (-1, 1), (0, 255), clamp=True)`` -> ``move_channel(to="last")`` -> ``.to(torch.uint8)``
+    (inference.py:337-343) fused into one pass; ``.cpu().numpy()`` of the result is what PIL takes."""
+    require_hip(images, "images_to_uint8")
+    if images.ndim != 4:
+        raise ValueError("images must be (B, C, H, W)")
+    old_min, old_max = old_range
+    if old_max == old_min:
+        raise ValueError("old_range is empty")
+    x = images.contiguous()
+    b, c, h, w = x.shape
+    out = torch.empty(b, h, w, c, dtype=torch.uint8, device=x.device)
+    check(_lib.lib().dm_images_to_u8(x.data_ptr(), _dm_dtype(x, "images_to_uint8"), b, c, h * w, float(old_min),
+                                     float(old_max - old_min), 255.0, 0.0, 0.0, 255.0, out.data_ptr(), stream_of(x)),
+          "images_to_u8")
+    return out

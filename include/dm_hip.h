@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 2
+#define DM_ABI_VERSION 3
 
 #define DM_F32 0
 #define DM_BF16 1
@@ -176,6 +176,17 @@ int dm_axpbypcz(const float* x, float alpha, const float* y, float beta, const f
  * rows = batch*seq; table fp32 [vocab][dim]; pos fp32 [seq][dim]. */
 int dm_embed_tokens(const long long* tokens, const float* table, const float* pos, void* out, long ld, int rows,
                     int seq, int dim, int vocab, int dtype, hipStream_t stream);
+
+/* y = ((x - old_min) / old_span) * new_span + new_min, optionally clamped to [lo, hi]; every step separately
+ * rounded in the tensor's dtype (fp32 or bf16).  Replaces rescale (scripts/utils.py:15-53); the host passes
+ * old_span = old_max - old_min and new_span = new_max - new_min as the reference forms them. */
+int dm_rescale(const void* x, void* y, long n, int dtype, float old_min, float old_span, float new_span,
+               float new_min, int clamp, float lo, float hi, hipStream_t stream);
+/* (B, C, H, W) images -> rescaled as above, clamped to [lo, hi] (within [0, 255]), truncated to uint8 and
+ * stored (B, H, W, C).  Replaces the post-processing chain of scripts/inference.py:337-343
+ * (rescale(..., clamp=True) -> move_channel(to="last") -> .to(torch.uint8)) in one pass.  hw = H*W. */
+int dm_images_to_u8(const void* x, int dtype, int batch, int c, long hw, float old_min, float old_span,
+                    float new_span, float new_min, float lo, float hi, unsigned char* out, hipStream_t stream);
 
 /* Layout / dtype plumbing around the model boundary (fp32 NCHW outside, [rows][C] inside). */
 int dm_nchw_to_rows(const float* src, int batch, int c, int hw, void* dst, long ld, int cpad, int dtype,
