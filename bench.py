@@ -141,6 +141,12 @@ def main():
         lat = sched.sample(model, shape, context, gen, device)
         return gather_latents(lat) if world > 1 else lat
 
+    # set-up, outside warm-up and timing: weight packing and the per-shape GEMM tile/split autotune run on the
+    # first forward of a process (like a compile step); a 2-step sampling call triggers both
+    setup = DDPMScheduler(num_train_timesteps=2, clip_sample=True)
+    setup.use_hip_graph = False
+    setup.sample(model, shape, clip(tokens).float() if clip is not None else ctx, gen, device)
+    del setup
     for _ in range(args.warmup):
         one_step()
     if world > 1:

@@ -23,6 +23,8 @@ TILE_DIMS = {TILE_128x128: (128, 128), TILE_64x128: (64, 128), TILE_64x64: (64, 
              TILE_D32x64_S4: (32, 64), TILE_D256x64_S3: (256, 64), TILE_D128x64_S4: (128, 64)}
 TILE_D256x64_S2, TILE_D128x64_S2, TILE_D64x64_S2 = 20, 21, 22
 TILE_D256x256_S2 = 23
+TILE_E128x128, TILE_E128x64, TILE_E64x64, TILE_E64x128 = 24, 25, 26, 27  # early-refill loop, 2 LDS buffers
+TILE_DIMS.update({TILE_E128x128: (128, 128), TILE_E128x64: (128, 64), TILE_E64x64: (64, 64), TILE_E64x128: (64, 128)})
 TILE_DIMS.update({TILE_D256x64_S2: (256, 64), TILE_D128x64_S2: (128, 64), TILE_D64x64_S2: (64, 64),
                   TILE_D256x256_S2: (256, 256)})
 ALL_TILES = tuple(TILE_DIMS)

@@ -5,9 +5,12 @@
 // A is the activation matrix (rows = pixels/tokens, channel-contiguous).  In conv mode the
 // k axis is (tap, cin) and row m = (b, y, x) gathers its 3x3 neighbourhood on the fly from an
 // NHWC image (zero padding 1; stride 1 or 2; optional nearest x2 upsampling of the input), so
-// no im2col buffer ever exists.  W is a pre-packed weight matrix [Npad][Kpad], k-contiguous,
-// zero padded, rows permuted inside every group of 64 so that each lane ends up owning 16
-// consecutive output columns (see pack order below).
+// no im2col buffer ever exists.  W is a pre-packed weight matrix of Npad x Kpad elements, zero padded,
+// rows permuted inside every group of 64 so that each lane ends up owning 16 consecutive output
+// columns (see pack order below), and stored blocked as [Npad/64][Kpad/BK][64 rows][128 bytes]: the
+// k-tile of a 64-row group is one contiguous 8 KiB piece and the group's whole K panel one contiguous
+// stream, so weight-bound shapes (few rows of A) read HBM in long bursts instead of 128-byte pieces
+// that are a full weight row apart.
 //
 // Block tile BM x BN x (128 bytes of k); 16x16 MFMA fragments; each wave owns a
 // (16*FM) x 64 sub-tile.  LDS tiles are 128-byte rows with an XOR swizzle of the 16-byte chunk
@@ -62,6 +65,13 @@ struct GemmArgs {
 __device__ __attribute__((aligned(16))) uint32_t g_zero16[4];
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// Byte offset of packed weight row `row`, k-tile `kt`, in the blocked image [Npad/64][nkt][64][128 B];
+// from one k-tile to the next a row's piece moves by W_KTILE_STEP bytes.
+constexpr int W_KTILE_STEP = 64 * 128;
+__device__ __forceinline__ long w_block_offset(int row, int nkt, int kt) {
+    return (((long)(row >> 6) * nkt + kt) * 64 + (row & 63)) * 128;
+}
 
 // XCD-aware tile id: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous run
 // of logical tiles so that neighbours sharing A rows / W columns hit the same L2.  Bijective for any nblk.
@@ -169,6 +179,41 @@ __device__ __forceinline__ void mma_tile(f32x4 (&acc)[FM][4], const char* sa, co
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) Mma16<T>::mma(acc[i][j], wf[j], af[i]);
+        }
+    }
+}
+
+// The same k-tile in two steps, for the loop that refills an LDS buffer as soon as its contents sit in
+// registers: all fragment reads of the tile, then (after the caller's barrier and refill) all MFMAs.
+template <typename T, int FM>
+__device__ __forceinline__ void read_tile_frags(u32x4 (&af)[2][FM], u32x4 (&wf)[2][4], const char* sa, const char* sw,
+                                                int arow0, int wrow0, int fr, int fq) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[ks][j] = *reinterpret_cast<const u32x4*>(sw + swz(wrow0 + j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[ks][i] = *reinterpret_cast<const u32x4*>(sa + swz(arow0 + i * 16 + fr, ks * 4 + fq));
+    }
+}
+template <typename T, int FM>
+__device__ __forceinline__ void mfma_tile_frags(f32x4 (&acc)[FM][4], const u32x4 (&af)[2][FM], const u32x4 (&wf)[2][4]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[ks][j][e]),
+                                                                        __uint_as_float(af[ks][i][e]), acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma16<T>::mma(acc[i][j], wf[ks][j], af[ks][i]);
         }
     }
 }
@@ -433,11 +478,25 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FM][4],
     }
 }
 
+// Wait until at most min(young, MAXY) k-tiles of LOADS LDS-DMA instructions each are still outstanding
+// (loads retire in order, so everything older has landed).  The count must be an immediate: one compare per
+// candidate, the steady state (young >= MAXY) taking the first.
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int LOADS, int MAXY> __device__ __forceinline__ void wait_young(int young) {
+    if constexpr (MAXY == 0) {
+        wait_vm<0>();
+    } else {
+        if (young >= MAXY) wait_vm<MAXY * LOADS>();
+        else wait_young<LOADS, MAXY - 1>(young);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // direct-to-LDS main loop
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool CONV>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool CONV, bool EARLY = false>
 __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
+    static_assert(!EARLY || STAGES == 2, "the early-refill loop runs on two LDS buffers");
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int FM = BM / (16 * WAVES_M);
     static_assert(BN == 64 * WAVES_N, "each wave owns 64 output columns");
@@ -449,7 +508,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
     constexpr int W_IT = BN * 8 / NT;
     constexpr int LOADS = A_IT + W_IT;           // LDS-DMA instructions per thread per k-tile
     constexpr int STAGE_BYTES = (BM + BN) * 128;
-    static_assert(STAGES >= 2 && STAGES <= 4 && (STAGES - 2) * LOADS <= 63, "ring depth / vmcnt field");
+    static_assert(STAGES >= 2 && STAGES <= 8 && (STAGES - 2) * LOADS <= 63, "ring depth / vmcnt field");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -512,7 +571,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
         const char* w_ptr[W_IT];
 #pragma unroll
         for (int it = 0; it < W_IT; ++it)
-            w_ptr[it] = p.W + ((long)(n0 + it * (NT / 8) + (tid >> 3)) * p.Kpad + (long)kt0 * BK + lchunk * EPC) * sizeof(T);
+            w_ptr[it] = p.W + w_block_offset(n0 + it * (NT / 8) + (tid >> 3), nkt, kt0) + lchunk * 16;
         int kc = kt0 * BK + lchunk * EPC, tap = 0;
         if (CONV) {
             tap = kc / p.Cin;
@@ -593,7 +652,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
             for (int it = 0; it < W_IT; ++it) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[it],
                                                  (__attribute__((address_space(3))) void*)(sw + it * (NT * 16)), 16, 0, 0);
-                w_ptr[it] += BK * sizeof(T);
+                w_ptr[it] += W_KTILE_STEP;
             }
         };
 
@@ -606,6 +665,27 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
         f32x4 ln_cs[4];
         ln_row_stats<FM>(p, m0 + wm * 16 * FM, n0 + wn * 64, fr, fq, ln_mu, ln_rs, ln_cs);
 
+        if constexpr (EARLY) {
+            // Two LDS buffers, two k-tiles in flight: a tile's fragments are all read into registers first, a
+            // second barrier then frees its buffer, and the tile two steps ahead is requested into it before
+            // the MFMAs start.  Every request so has almost two iterations to land instead of one.
+            if (kt0 < kt1) issue(kt0, 0);
+            if (kt0 + 1 < kt1) issue(kt0 + 1, 1);
+            int stage = 0;
+            for (int kt = kt0; kt < kt1; ++kt) {
+                wait_young<LOADS, 1>(kt1 - 1 - kt);  // tile kt has landed; tile kt+1 may still be in flight
+                __builtin_amdgcn_s_barrier();        // ... and every wave's share of it is visible
+                const char* sa = smem + stage * STAGE_BYTES;
+                u32x4 af[2][FM], wf[2][4];
+                read_tile_frags<T, FM>(af, wf, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();        // all waves hold tile kt in registers: its buffer is free
+                if (kt + 2 < kt1) issue(kt + 2, stage);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tile_frags<T, FM>(acc, af, wf);
+                stage ^= 1;
+            }
+        } else {
         // prologue: up to STAGES-1 tiles in flight
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
@@ -616,14 +696,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
             // tile kt has landed once only the younger tiles in flight (at most STAGES-2, fewer at the end
             // of the run) are outstanding; the barrier makes every wave's share visible and retires all
             // reads of the stage refilled below
-            if constexpr (STAGES == 2) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                const int young = kt1 - 1 - kt;
-                if (STAGES >= 4 && young >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
-                else if (young >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            wait_young<LOADS, STAGES - 2>(kt1 - 1 - kt);
             __builtin_amdgcn_s_barrier();
             int nstage = stage + STAGES - 1;
             if (nstage >= STAGES) nstage -= STAGES;
@@ -631,6 +704,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
             const char* sa = smem + stage * STAGE_BYTES;
             mma_tile<T, FM>(acc, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq);
             if (++stage == STAGES) stage = 0;
+        }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -691,15 +765,15 @@ constexpr int dma_min_waves(int bm, int bn, int waves, int stages) {
     const int w = (blocks < 8 ? blocks : 8) * waves / 4;
     return w < 1 ? 1 : (w > 4 ? 4 : w);
 }
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool EARLY = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_M* WAVES_N, STAGES)) void gemm_dma_kernel(
     GemmArgs p) {
-    gemm_dma_body<T, BM, BN, WAVES_M, WAVES_N, STAGES, false>(p);
+    gemm_dma_body<T, BM, BN, WAVES_M, WAVES_N, STAGES, false, EARLY>(p);
 }
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool EARLY = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_M* WAVES_N, STAGES)) void conv3x3_igemm_kernel(
     GemmArgs p) {
-    gemm_dma_body<T, BM, BN, WAVES_M, WAVES_N, STAGES, true>(p);
+    gemm_dma_body<T, BM, BN, WAVES_M, WAVES_N, STAGES, true, EARLY>(p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -744,7 +818,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_reg_kernel(GemmArg
     const char* w_ptr[W_IT];
 #pragma unroll
     for (int it = 0; it < W_IT; ++it)
-        w_ptr[it] = p.W + ((long)(n0 + it * (NT / 8) + (tid >> 3)) * p.Kpad + chunk * EPC) * sizeof(T);
+        w_ptr[it] = p.W + w_block_offset(n0 + it * (NT / 8) + (tid >> 3), nkt, 0) + chunk * 16;
     int kc = kt0 * BK + chunk * EPC, tap = 0;
     if (p.conv) {
         tap = kc / p.Cin;
@@ -774,7 +848,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_reg_kernel(GemmArg
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int row = it * (NT / 8) + (tid >> 3);
-            rw[it] = ldg16(w_ptr[it] + (long)kt * BK * sizeof(T), row < BN);
+            rw[it] = ldg16(w_ptr[it] + (long)kt * W_KTILE_STEP, row < BN);
         }
     };
     auto store_tile = [&](int buf) {
@@ -871,11 +945,12 @@ template <typename T, int BM, int BN, int WM, int WN> int launch_reg(const GemmA
     const TileInfo t{BM, BN, WM * WN * 64, 2 * (BM + BN) * 128};
     return launch_kernel(gemm_reg_kernel<T, BM, BN, WM, WN>, done, t, a, s);
 }
-template <typename T, int BM, int BN, int WM, int WN, int ST> int launch_dma(const GemmArgs& a, hipStream_t s) {
+template <typename T, int BM, int BN, int WM, int WN, int ST, bool EARLY = false>
+int launch_dma(const GemmArgs& a, hipStream_t s) {
     static bool done = false, done_conv = false;
     const TileInfo t{BM, BN, WM * WN * 64, ST * (BM + BN) * 128};
-    if (a.conv) return launch_kernel(conv3x3_igemm_kernel<T, BM, BN, WM, WN, ST>, done_conv, t, a, s);
-    return launch_kernel(gemm_dma_kernel<T, BM, BN, WM, WN, ST>, done, t, a, s);
+    if (a.conv) return launch_kernel(conv3x3_igemm_kernel<T, BM, BN, WM, WN, ST, EARLY>, done_conv, t, a, s);
+    return launch_kernel(gemm_dma_kernel<T, BM, BN, WM, WN, ST, EARLY>, done, t, a, s);
 }
 
 template <typename T> int launch_typed(const GemmArgs& a, int cfg, hipStream_t s) {
@@ -898,6 +973,10 @@ template <typename T> int launch_typed(const GemmArgs& a, int cfg, hipStream_t s
         case DM_TILE_D128x64_S2: return launch_dma<T, 128, 64, 4, 1, 2>(a, s);
         case DM_TILE_D64x64_S2: return launch_dma<T, 64, 64, 4, 1, 2>(a, s);
         case DM_TILE_D256x256_S2: return launch_dma<T, 256, 256, 2, 4, 2>(a, s);
+        case DM_TILE_E128x128: return launch_dma<T, 128, 128, 2, 2, 2, true>(a, s);
+        case DM_TILE_E128x64: return launch_dma<T, 128, 64, 4, 1, 2, true>(a, s);
+        case DM_TILE_E64x64: return launch_dma<T, 64, 64, 4, 1, 2, true>(a, s);
+        case DM_TILE_E64x128: return launch_dma<T, 64, 128, 2, 2, 2, true>(a, s);
         default: return DM_ERR_ARG;
     }
 }
@@ -906,9 +985,10 @@ template <typename T> int launch_typed(const GemmArgs& a, int cfg, hipStream_t s
 int tile_wave_rows(int cfg) {
     switch (cfg) {
         case DM_TILE_64x64: case DM_TILE_32x64: case DM_TILE_D64x64_S4: case DM_TILE_D64x64_S2: case DM_TILE_D32x64_S4:
+        case DM_TILE_E64x64:
             return 16;
         case DM_TILE_64x128: case DM_TILE_D64x128_S3: case DM_TILE_D64x128_S4: case DM_TILE_D128x64_S4:
-        case DM_TILE_D128x64_S2:
+        case DM_TILE_D128x64_S2: case DM_TILE_E128x64: case DM_TILE_E64x128:
             return 32;
         case DM_TILE_D256x256_S2: return 128;
         default: return 64;
@@ -917,15 +997,17 @@ int tile_wave_rows(int cfg) {
 
 int tile_dims(int cfg, int* bm, int* bn) {
     switch (cfg) {
-        case DM_TILE_128x128: case DM_TILE_D128x128_S2: case DM_TILE_D128x128_S3: *bm = 128; *bn = 128; return 0;
-        case DM_TILE_64x128: case DM_TILE_D64x128_S3: case DM_TILE_D64x128_S4: *bm = 64; *bn = 128; return 0;
+        case DM_TILE_128x128: case DM_TILE_D128x128_S2: case DM_TILE_D128x128_S3: case DM_TILE_E128x128:
+            *bm = 128; *bn = 128; return 0;
+        case DM_TILE_64x128: case DM_TILE_D64x128_S3: case DM_TILE_D64x128_S4: case DM_TILE_E64x128:
+            *bm = 64; *bn = 128; return 0;
         case DM_TILE_64x64: case DM_TILE_D64x64_S4: *bm = 64; *bn = 64; return 0;
         case DM_TILE_256x128: case DM_TILE_D256x128_S3: *bm = 256; *bn = 128; return 0;
         case DM_TILE_32x64: case DM_TILE_D32x64_S4: *bm = 32; *bn = 64; return 0;
         case DM_TILE_D256x64_S3: *bm = 256; *bn = 64; return 0;
-        case DM_TILE_D128x64_S4: case DM_TILE_D128x64_S2: *bm = 128; *bn = 64; return 0;
+        case DM_TILE_D128x64_S4: case DM_TILE_D128x64_S2: case DM_TILE_E128x64: *bm = 128; *bn = 64; return 0;
         case DM_TILE_D256x64_S2: *bm = 256; *bn = 64; return 0;
-        case DM_TILE_D64x64_S2: *bm = 64; *bn = 64; return 0;
+        case DM_TILE_D64x64_S2: case DM_TILE_E64x64: *bm = 64; *bn = 64; return 0;
         case DM_TILE_D256x256_S2: *bm = 256; *bn = 256; return 0;
         default: return 1;
     }
@@ -1086,7 +1168,7 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
                        d->workspace_bytes < dm_gemm_workspace_bytes(d->m, d->n, splitk)))
         return DM_ERR_ARG;
     // packed weights must cover every tile row that will be read
-    if (d->npad < ((d->n + bn - 1) / bn) * bn) return DM_ERR_ARG;
+    if (d->npad % 64 || d->npad < ((d->n + bn - 1) / bn) * bn) return DM_ERR_ARG;  // 64-row groups of the blocked image
 
     GemmArgs a;
     a.A = static_cast<const char*>(d->a);

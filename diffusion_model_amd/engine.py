@@ -112,6 +112,7 @@ class Engine:
         self._gn_auto: Dict[int, dict] = {}   # data_ptr -> record of a tensor written by one GEMM
         self._ln_stats: Dict[int, torch.Tensor] = {}  # data_ptr -> [rows][2] fp64 row sums (folded LayerNorm)
         self.fuse_ln = os.environ.get("DM_FUSE_LN", "1") == "1"
+        self.tune_early = os.environ.get("DM_TUNE_EARLY", "1") != "0"
         self.fuse_gn_stats = os.environ.get("DM_FUSE_GN_STATS", "1") == "1"
         self.profile: Optional[dict] = None  # kernel class -> [events...] when profiling
         self._order_cache: Dict[Tuple[int, int, bool], torch.Tensor] = {}
@@ -209,7 +210,8 @@ class Engine:
             self._order_cache[key] = torch.tensor(list(arr), dtype=torch.long, device=self.device)
         return self._order_cache[key]
 
-    def pack_matrix(self, w2d: torch.Tensor, bias: Optional[torch.Tensor], geglu=False, conv_cin=0) -> PackedWeight:
+    def pack_matrix(self, w2d: torch.Tensor, bias: Optional[torch.Tensor], geglu=False, conv_cin=0,
+                    rowsum=False) -> PackedWeight:
         n, k = w2d.shape
         npad, kpad = _rup(n, 256), _rup(k, self.bk)  # widest block tile is 256 columns
         order = self._order(n, npad, geglu)
@@ -217,7 +219,12 @@ class Engine:
         valid = order >= 0
         wp[valid, :k] = w2d.detach().to(self.device)[order[valid]].to(self.dtype)
         b = None if bias is None else bias.detach().to(device=self.device, dtype=torch.float32).contiguous()
-        return PackedWeight(wp, n, k, npad, kpad, b, geglu, conv_cin)
+        pw = PackedWeight(None, n, k, npad, kpad, b, geglu, conv_cin)
+        if rowsum:  # per packed row, of the values the MFMA really sees (after rounding to the engine dtype)
+            pw.colsum = wp.float().sum(dim=1).contiguous()
+        # blocked image [npad/64][kpad/bk][64][bk]: the k-tile of a 64-row group is one contiguous 8 KiB piece
+        pw.w = wp.view(npad // 64, 64, kpad // self.bk, self.bk).permute(0, 2, 1, 3).contiguous()
+        return pw
 
     def pack_linear(self, lin: torch.nn.Linear, geglu=False, ln: Optional[torch.nn.LayerNorm] = None) -> PackedWeight:
         """``ln``: the LayerNorm whose output is this Linear's only input.  Its scale goes into the weights
@@ -231,8 +238,7 @@ class Engine:
         bias = w @ beta
         if lin.bias is not None:
             bias = bias + lin.bias.detach().to(self.device, torch.float32)
-        pw = self.pack_matrix(w * gamma[None, :], bias, geglu)
-        pw.colsum = pw.w.float().sum(dim=1).contiguous()  # of the values the MFMA really sees (after rounding)
+        pw = self.pack_matrix(w * gamma[None, :], bias, geglu, rowsum=True)
         pw.ln_eps = float(ln.eps)
         return pw
 
@@ -364,7 +370,9 @@ class Engine:
     # Candidate (tile, split-K) pairs are timed once per distinct problem on the real operands (the
     # launch is idempotent: it only rewrites the output) and the winner is cached for the process.
     _TUNE_TILES = (_lib.TILE_D256x128_S3, _lib.TILE_D128x128_S2, _lib.TILE_D256x64_S2, _lib.TILE_D128x64_S2,
-                   _lib.TILE_D64x128_S3, _lib.TILE_D64x64_S4, _lib.TILE_D64x64_S2, _lib.TILE_D32x64_S4)
+                   _lib.TILE_D64x128_S3, _lib.TILE_D64x64_S4, _lib.TILE_D64x64_S2, _lib.TILE_D32x64_S4,
+                   _lib.TILE_E128x128, _lib.TILE_E128x64)
+    _EARLY_REFILL = (_lib.TILE_E128x128, _lib.TILE_E128x64)  # measured to win only on some bf16 shapes
     _TUNE_SK = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)
     _TUNE_STREAMK = (256, 512, 768, 1024)  # blocks sharing the (tile, k-tile) work list
     _TUNE_STREAMK_MULT = (2, 3, 4, 6, 8, 12, 16, 24)  # ... and whole multiples of the tile count
@@ -410,6 +418,8 @@ class Engine:
         for tile in self._TUNE_TILES:
             bm, bn = _lib.TILE_DIMS[tile]
             if d.npad < _rup(d.n, bn) or (tile == _lib.TILE_D256x128_S3 and d.m < 2048):
+                continue
+            if tile in self._EARLY_REFILL and (self.dtype != torch.bfloat16 or not self.tune_early):
                 continue
             blocks = ((d.m + bm - 1) // bm) * ((d.n + bn - 1) // bn)
             for sk in self._TUNE_SK:

@@ -52,6 +52,12 @@ extern "C" {
 #define DM_TILE_D128x64_S2 21
 #define DM_TILE_D64x64_S2 22
 #define DM_TILE_D256x256_S2 23 /* 8 waves, each 128x64 */
+/* E: two LDS buffers, a k-tile's fragments are read into registers before its buffer is refilled with the
+ * tile two steps ahead (two tiles in flight at the LDS footprint, hence occupancy, of a 2-stage ring) */
+#define DM_TILE_E128x128 24
+#define DM_TILE_E128x64 25
+#define DM_TILE_E64x64 26
+#define DM_TILE_E64x128 27
 
 int dm_abi_version(void);
 
@@ -65,7 +71,9 @@ int dm_abi_version(void);
 typedef struct DmGemmDesc {
     const void* a;        /* activations [m][lda] (conv: NHWC image rows (b, y, x)) */
     long lda;
-    const void* w;        /* packed weights [npad][kpad], k contiguous */
+    const void* w;        /* packed weights, npad x kpad elements, rows in dm_pack_weight_order order, stored
+                           * blocked as [npad/64][kpad/bk][64 rows][bk] with bk = 128 bytes of k (32 fp32 /
+                           * 64 bf16): one k-tile of a 64-row group is a contiguous 8 KiB piece */
     void* c;              /* output [m][ldc] (or fp32 NCHW); c, r 16-byte aligned, ldc, ldr multiples of 16 bytes */
     long ldc;
     const float* bias;    /* [n] fp32 or NULL */

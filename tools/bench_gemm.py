@@ -21,6 +21,7 @@ ap.add_argument("--tiles", default="1,11,12,13")
 ap.add_argument("--sk", default="1")
 ap.add_argument("--shapes", default="all")
 ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--apad", type=int, default=0, help="extra elements in the row stride of A (channel-interleave experiments)")
 args = ap.parse_args()
 
 dev = torch.device("cuda", 0)
@@ -58,7 +59,7 @@ def run(kind, cin, cout, hw):
         conv = torch.nn.Conv2d(cin, cout, 3, padding=1).to(dev)
         pw = eng.pack_conv3x3(conv)
         m = B * hw * hw
-        a = (torch.randn(m, cin, device=dev, generator=gen)).to(dt)
+        a = (torch.randn(m, cin + args.apad, device=dev, generator=gen)).to(dt)[:, :cin]
         geom = dict(batch=B, hin=hw, win=hw, hout=hw, wout=hw, cin_real=cin)
         flops = 2.0 * m * cout * 9 * cin
         label = f"conv {cin:4d}->{cout:4d} @{hw:2d}^2 m={m}"
@@ -70,7 +71,7 @@ def run(kind, cin, cout, hw):
         lin = torch.nn.Linear(cin, cout).to(dev)
         geglu = cout >= 8 * cin
         pw = eng.pack_linear(lin, geglu=geglu)
-        a = (torch.randn(m, cin, device=dev, generator=gen)).to(dt)
+        a = (torch.randn(m, cin + args.apad, device=dev, generator=gen)).to(dt)[:, :cin]
         geom = None
         flops = 2.0 * m * cout * cin
         label = f"gemm k={cin:4d} n={cout:5d} m={m}" + (" geglu" if geglu else "")
