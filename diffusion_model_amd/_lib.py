@@ -52,6 +52,7 @@ class GemmDesc(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_long),
         ("stats", C.c_void_p), ("ld_stats", C.c_long),
         ("ln_in", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_out", C.c_void_p),
+        ("a2", C.c_void_p), ("lda2", C.c_long), ("cin2", C.c_int),
     ]
 
 
@@ -111,7 +112,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dm_abi_version() != 3:
+        if handle.dm_abi_version() != 4:
             raise RuntimeError("libdm_hip.so ABI version mismatch; rebuild with `python build.py`")
         _lib = handle
     return _lib

@@ -47,6 +47,9 @@ struct GemmArgs {
     long ldr;
     int M, N, K, Kpad;
     int conv, Hin, Win, Hout, Wout, Cin, stride, up;
+    const char* A2;  // conv only: a second, pointwise operand (tap 9: the pixel itself, Cin2 channels) appended to k
+    long lda2;
+    int Cin2;
     int epi;
     int splitk;
     float* partial;
@@ -574,7 +577,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
             w_ptr[it] = p.W + w_block_offset(n0 + it * (NT / 8) + (tid >> 3), nkt, kt0) + lchunk * 16;
         int kc = kt0 * BK + lchunk * EPC, tap = 0;
         if (CONV) {
-            tap = kc / p.Cin;
+            tap = min(kc / p.Cin, 9);  // tap 9: the appended pointwise operand (only with A2)
             kc -= tap * p.Cin;
         }
         // Fast paths: convolution with Cin a multiple of the k-tile (the tap is the same for every thread of
@@ -584,6 +587,18 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
         int a_step[A_IT];
         int c0 = 0;  // channel offset of the next k-tile inside its tap
         auto set_tap = [&]() {
+            if (tap >= 9) {
+                // appended pointwise operand: the output pixel's own row of the second tensor (the launcher
+                // admits it only for stride-1, same-size convolutions, where output and input pixels coincide)
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) {
+                    const bool ok = rows.ok[it] && p.A2 != nullptr;
+                    const long pix = rows.off[it] + (long)rows.y[it] * p.Win + rows.x[it];
+                    a_ptr[it] = ok ? p.A2 + (pix * p.lda2 + c0 + lchunk * EPC) * sizeof(T) : zsrc;
+                    a_step[it] = ok ? BK * (int)sizeof(T) : 0;
+                }
+                return;
+            }
 #pragma unroll
             for (int it = 0; it < A_IT; ++it) {
                 long e;
@@ -618,7 +633,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
                 }
                 if (CONV) {
                     c0 += BK;
-                    if (c0 == p.Cin) {
+                    if (c0 == p.Cin && tap < 9) {
                         c0 = 0;
                         ++tap;
                         set_tap();
@@ -1125,7 +1140,13 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     if (d->bias && !dm_aligned16(d->bias)) return DM_ERR_ALIGN;
     if (d->rowbias && (!dm_aligned16(d->rowbias) || d->ld_rowbias % 4)) return DM_ERR_ALIGN;
     if (d->conv) {
-        if (d->cin % epc || d->k != 9 * d->cin) return DM_ERR_ARG;
+        if (d->cin % epc || d->k != 9 * d->cin + (d->a2 ? d->cin2 : 0)) return DM_ERR_ARG;
+        if (d->a2) {
+            // appended pointwise operand: direct-to-LDS tiles on their aligned fast path, same-size convolution
+            if (d->cin2 <= 0 || d->cin % bk || d->cin2 % bk || d->stride != 1 || d->up || d->lda2 % epc ||
+                !dm_aligned16(d->a2))
+                return DM_ERR_ARG;
+        }
         if (d->stride != 1 && d->stride != 2) return DM_ERR_ARG;
         if (d->up && (d->stride != 1 || d->hout != 2 * d->hin || d->wout != 2 * d->win)) return DM_ERR_ARG;
         if (!d->up && (d->hout != (d->hin + 2 - 3) / d->stride + 1 || d->wout != (d->win + 2 - 3) / d->stride + 1))
@@ -1145,6 +1166,7 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     if (tile == DM_TILE_AUTO) dm_gemm_plan(d->dtype, d->m, d->n, d->k, d->epi, &tile, &splitk);
     int bm, bn;
     if (tile_dims(tile, &bm, &bn)) return DM_ERR_ARG;
+    if (d->conv && d->a2 && tile < DM_TILE_D128x128_S2) return DM_ERR_ARG;  // only the direct-to-LDS loop knows tap 9
     // folded / produced LayerNorm statistics live in the epilogue: not with the separate split-K reduction
     if ((d->ln_in || d->ln_out) && splitk > 1) return DM_ERR_ARG;
     if (d->ln_in && (!d->ln_colsum || d->conv || !dm_aligned16(d->ln_colsum) || (reinterpret_cast<uintptr_t>(d->ln_in) & 7u)))
@@ -1185,6 +1207,7 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     a.M = d->m; a.N = d->n; a.K = d->k; a.Kpad = d->kpad;
     a.conv = d->conv; a.Hin = d->hin; a.Win = d->win; a.Hout = d->hout; a.Wout = d->wout;
     a.Cin = d->cin; a.stride = d->stride; a.up = d->up;
+    a.A2 = d->conv ? static_cast<const char*>(d->a2) : nullptr; a.lda2 = d->lda2; a.Cin2 = d->cin2;
     a.epi = d->epi;
     a.splitk = splitk;
     a.partial = static_cast<float*>(d->workspace);

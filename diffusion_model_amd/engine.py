@@ -62,13 +62,14 @@ class Arena:
 
 class PackedWeight:
     """Weight matrix in the GEMM kernel's layout plus its fp32 bias."""
-    __slots__ = ("w", "n", "k", "npad", "kpad", "bias", "geglu", "conv_cin", "colsum", "ln_eps")
+    __slots__ = ("w", "n", "k", "npad", "kpad", "bias", "geglu", "conv_cin", "colsum", "ln_eps", "skip_cin")
 
     def __init__(self, w, n, k, npad, kpad, bias, geglu=False, conv_cin=0):
         self.w, self.n, self.k, self.npad, self.kpad = w, n, k, npad, kpad
         self.bias, self.geglu, self.conv_cin = bias, geglu, conv_cin
         self.colsum = None  # set when a LayerNorm is folded in: sum over k of every packed row (fp32)
         self.ln_eps = 0.0
+        self.skip_cin = 0  # conv3x3 packed with a pointwise term over a second tensor: its channel count
 
 
 class Engine:
@@ -113,6 +114,7 @@ class Engine:
         self._ln_stats: Dict[int, torch.Tensor] = {}  # data_ptr -> [rows][2] fp64 row sums (folded LayerNorm)
         self.fuse_ln = os.environ.get("DM_FUSE_LN", "1") == "1"
         self.tune_early = os.environ.get("DM_TUNE_EARLY", "1") != "0"
+        self.fuse_skip = os.environ.get("DM_FUSE_SKIP", "1") != "0"  # residual_layer folded into the second conv
         self.fuse_gn_stats = os.environ.get("DM_FUSE_GN_STATS", "1") == "1"
         self.profile: Optional[dict] = None  # kernel class -> [events...] when profiling
         self._order_cache: Dict[Tuple[int, int, bool], torch.Tensor] = {}
@@ -245,13 +247,28 @@ class Engine:
     def pack_conv1x1(self, conv: torch.nn.Conv2d) -> PackedWeight:
         return self.pack_matrix(conv.weight.reshape(conv.out_channels, conv.in_channels), conv.bias)
 
-    def pack_conv3x3(self, conv: torch.nn.Conv2d) -> PackedWeight:
+    def pack_conv3x3(self, conv: torch.nn.Conv2d, skip: Optional[torch.nn.Conv2d] = None) -> PackedWeight:
+        """``skip``: a 1x1 convolution over a second tensor whose result is added to this convolution's output
+        (ResidualBlock.residual_layer); its weights are appended to the k axis and its bias folded in, so the
+        sum is formed inside one launch (``gemm(..., conv=dict(..., skip=x))``)."""
         w = conv.weight.detach().permute(0, 2, 3, 1)  # (Cout, 3, 3, Cin): k = tap*Cin + c
         cin = conv.in_channels
         cpad = _rup(cin, 8)
         if cpad != cin:
             w = torch.nn.functional.pad(w, (0, cpad - cin))
-        return self.pack_matrix(w.reshape(conv.out_channels, 9 * cpad), conv.bias, conv_cin=cpad)
+        w2d = w.reshape(conv.out_channels, 9 * cpad)
+        if skip is None:
+            return self.pack_matrix(w2d, conv.bias, conv_cin=cpad)
+        cin2 = skip.in_channels
+        if cpad % self.bk or cin2 % self.bk or skip.out_channels != conv.out_channels:
+            raise RuntimeError("pointwise term needs channel counts that are multiples of the k-tile")
+        w2d = torch.cat([w2d, skip.weight.detach().reshape(skip.out_channels, cin2)], dim=1)
+        bias = conv.bias.detach().float()
+        if skip.bias is not None:
+            bias = bias + skip.bias.detach().float()
+        pw = self.pack_matrix(w2d, bias, conv_cin=cpad)
+        pw.skip_cin = cin2
+        return pw
 
     # ------------------------------------------------------------------ operators
     def gemm(self, a: torch.Tensor, pw: PackedWeight, out: Optional[torch.Tensor] = None, *, bias=True,
@@ -271,6 +288,13 @@ class Engine:
             d.cin, d.stride, d.up = pw.conv_cin, conv.get("stride", 1), conv.get("up", 0)
             if a.shape[1] != pw.conv_cin:
                 raise RuntimeError("conv input channel mismatch")
+            skip = conv.get("skip")
+            if (skip is None) != (pw.skip_cin == 0):
+                raise RuntimeError("weights packed with a pointwise term need its input (conv['skip']) and vice versa")
+            if skip is not None:
+                if skip.shape[0] != m or skip.shape[1] != pw.skip_cin:
+                    raise RuntimeError("pointwise input shape mismatch")
+                d.a2, d.lda2, d.cin2 = skip.data_ptr(), skip.stride(0), pw.skip_cin
             klass = "conv3x3"
         else:
             m = a.shape[0]
@@ -343,7 +367,7 @@ class Engine:
                 rec["parts"] += pw.n
             else:
                 rec["valid"] = False
-        with self._prof(klass, 2.0 * m * pw.n * (pw.k if conv is None else 9 * conv["cin_real"]),
+        with self._prof(klass, 2.0 * m * pw.n * (pw.k if conv is None else 9 * conv["cin_real"] + pw.skip_cin),
                         f"m={m} n={pw.n} k={pw.k} tile={tile.value} sk={sk.value} epi={d.epi}"
                         + (f" s={d.stride} up={d.up}" if conv is not None else "")):
             check(self.lib.dm_gemm(C.byref(d), self.stream), klass)

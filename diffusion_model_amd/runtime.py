@@ -50,6 +50,10 @@ def cached_pack(module: torch.nn.Module, eng: Engine, builder):
 
 def pack_residual_block(m, eng: Engine) -> NS:
     cin, cout = m.conv_feature.in_channels, m.conv_feature.out_channels
+    # the 1x1 residual_layer rides in the second convolution as extra k (one launch, no skip tensor) when the
+    # channel counts are whole k-tiles
+    fold = (eng.fuse_skip and isinstance(m.residual_layer, torch.nn.Conv2d) and cin % eng.bk == 0
+            and cout % eng.bk == 0)
     return NS(kind="res", cin=cin, cout=cout,
               gn1_w=_f32(eng, m.groupnorm_feature.weight), gn1_b=_f32(eng, m.groupnorm_feature.bias),
               gn1_eps=m.groupnorm_feature.eps,
@@ -57,9 +61,9 @@ def pack_residual_block(m, eng: Engine) -> NS:
               lt_w=_f32(eng, m.linear_time.weight), lt_b=_f32(eng, m.linear_time.bias),
               gn2_w=_f32(eng, m.groupnorm_merged.weight), gn2_b=_f32(eng, m.groupnorm_merged.bias),
               gn2_eps=m.groupnorm_merged.eps,
-              conv2=eng.pack_conv3x3(m.conv_merged),
-              res=None if isinstance(m.residual_layer, torch.nn.Identity) else eng.pack_conv1x1(m.residual_layer),
-              t_off=0)
+              conv2=eng.pack_conv3x3(m.conv_merged, skip=m.residual_layer if fold else None),
+              res=None if (fold or isinstance(m.residual_layer, torch.nn.Identity)) else eng.pack_conv1x1(m.residual_layer),
+              fold_skip=fold, t_off=0)
 
 
 def pack_self_attention(m, eng: Engine, ln=None) -> NS:
@@ -165,9 +169,12 @@ def run_residual_block(eng: Engine, pk: NS, x, batch: int, h: int, w: int, tproj
     a = eng.groupnorm(x, batch, hw, pk.gn1_w, pk.gn1_b, pk.gn1_eps, silu=True)
     a = eng.gemm(a, pk.conv1, rowbias=tproj, rows_per_batch=hw, conv=dict(geom, cin_real=pk.cin), gn_batch=batch)
     a = eng.groupnorm(a, batch, hw, pk.gn2_w, pk.gn2_b, pk.gn2_eps, silu=True)
-    skip = x if pk.res is None else eng.gemm(x, pk.res)
     # the block output is group-normalised by whatever follows (ResidualBlock, AttentionBlock or FinalLayer)
-    eng.gemm(a, pk.conv2, out=out, residual=skip, conv=dict(geom, cin_real=pk.cout), gn_batch=batch)
+    if pk.fold_skip:
+        eng.gemm(a, pk.conv2, out=out, conv=dict(geom, cin_real=pk.cout, skip=x), gn_batch=batch)
+    else:
+        skip = x if pk.res is None else eng.gemm(x, pk.res)
+        eng.gemm(a, pk.conv2, out=out, residual=skip, conv=dict(geom, cin_real=pk.cout), gn_batch=batch)
     eng.arena.release(mark)
     return out
 

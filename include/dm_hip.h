@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 3
+#define DM_ABI_VERSION 4
 
 #define DM_F32 0
 #define DM_BF16 1
@@ -114,6 +114,13 @@ typedef struct DmGemmDesc {
     const float* ln_colsum;
     float ln_eps;
     double* ln_out;
+    /* conv only: a pointwise (1x1) term over a second tensor appended to the k axis, k = 9*cin + cin2:
+     * out[m] += sum_c a2[m][c] * w[n][9*cin + c].  Folds ResidualBlock's residual_layer (blocks.py:42,70-72)
+     * into its second convolution.  Stride-1, same-size convolutions; cin and cin2 multiples of the k-tile
+     * (32 fp32 / 64 bf16); direct-to-LDS tiles.  NULL = none. */
+    const void* a2;
+    long lda2;
+    int cin2;
 } DmGemmDesc;
 
 int dm_gemm(const DmGemmDesc* d, hipStream_t stream);

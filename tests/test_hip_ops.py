@@ -257,6 +257,37 @@ def test_conv3x3_every_tile(eng, tile, sk):
         assert max_rel(eng.rows_to_nchw(out, b, cout, ho, wo), ref) < tol(eng.dtype), (cin, cout, stride, upx)
 
 
+@pytest.mark.parametrize("tile,sk", [(_lib.TILE_AUTO, 1)] + [(t, sk) for t in DMA_TILES for sk in (1, -24, -61)])
+def test_conv3x3_with_pointwise_term(eng, tile, sk):
+    """conv3x3(a) + conv1x1(x) in one launch (the residual_layer of a ResidualBlock riding in its second conv):
+    k runs over the nine taps and then over the second tensor's channels; work-list splits may start or end
+    inside either part."""
+    b, h, w = 2, 8, 6
+    for cin, cin2, cout in ((64, 128, 64), (128, 64, 192)):
+        a = tin("cp.a", (b, cin, h, w)); x = tin("cp.x", (b, cin2, h, w))
+        wt = tin("cp.w", (cout, cin, 3, 3), scale=1 / math.sqrt(9 * cin)); bias = tin("cp.b", (cout,))
+        w1 = tin("cp.w1", (cout, cin2, 1, 1), scale=1 / math.sqrt(cin2)); b1 = tin("cp.b1", (cout,))
+        conv = torch.nn.Conv2d(cin, cout, 3, padding=1); skip = torch.nn.Conv2d(cin2, cout, 1)
+        with torch.no_grad():
+            conv.weight.copy_(wt); conv.bias.copy_(bias); skip.weight.copy_(w1); skip.bias.copy_(b1)
+        pw = eng.pack_conv3x3(conv, skip=skip)
+        assert pw.skip_cin == cin2 and pw.k == 9 * cin + cin2
+        arows = eng.nchw_to_rows(a.to(eng.device)); xrows = eng.nchw_to_rows(x.to(eng.device))
+        ref = (F.conv2d(rnd(a, eng.dtype), rnd(wt, eng.dtype), bias, padding=1)
+               + F.conv2d(rnd(x, eng.dtype), rnd(w1, eng.dtype), b1))
+        eng.tile_override = None if tile == _lib.TILE_AUTO else (tile, sk)
+        out = eng.gemm(arows, pw, conv=dict(batch=b, hin=h, win=w, hout=h, wout=w, cin_real=cin, skip=xrows))
+        eng.tile_override = None
+        assert max_rel(eng.rows_to_nchw(out, b, cout, h, w), ref) < tol(eng.dtype), (cin, cin2, cout)
+    # the descriptor is refused where the term cannot be honoured: missing input, staged tiles, strided conv
+    with pytest.raises(RuntimeError):
+        eng.gemm(arows, pw, conv=dict(batch=b, hin=h, win=w, hout=h, wout=w, cin_real=cin))
+    eng.tile_override = (_lib.TILE_64x64, 1)
+    with pytest.raises(RuntimeError):
+        eng.gemm(arows, pw, conv=dict(batch=b, hin=h, win=w, hout=h, wout=w, cin_real=cin, skip=xrows))
+    eng.tile_override = None
+
+
 def test_conv3x3_nchw_epilogue_and_rowbias(eng):
     b, cin, cout, h, w = 2, 320, 4, 8, 8
     x = tin("n.x", (b, cin, h, w)); wt = tin("n.w", (cout, cin, 3, 3), scale=0.02); bias = tin("n.b", (cout,))
