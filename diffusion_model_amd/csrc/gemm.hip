@@ -47,7 +47,8 @@ struct GemmArgs {
     long ldr;
     int M, N, K, Kpad;
     int conv, Hin, Win, Hout, Wout, Cin, stride, up;
-    const char* A2;  // conv only: a second, pointwise operand (tap 9: the pixel itself, Cin2 channels) appended to k
+    const char* A2;  // second operand appended to the k axis, Cin2 elements per row: conv: a pointwise term (tap 9,
+                     // the pixel itself); dense: columns K-Cin2 .. K-1 of A come from this tensor instead
     long lda2;
     int Cin2;
     int epi;
@@ -109,6 +110,7 @@ __device__ __forceinline__ void init_rows(ARows<A_IT>& r, const GemmArgs& p, int
                 r.off[it] = (long)b * p.Hin * p.Win;
             } else {
                 r.off[it] = (long)m * p.lda;
+                r.y[it] = m;  // dense: the row index itself (second-operand addressing)
             }
         }
     }
@@ -607,6 +609,14 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
                 a_step[it] = ok ? BK * (int)sizeof(T) : 0;
             }
         };
+        // dense with a second operand: from k-tile kt_second on, A's columns come from A2 (same rows)
+        const int kt_second = (!CONV && p.A2) ? (p.K - p.Cin2) / BK : 0x7fffffff;
+        auto second_operand = [&](int kt) {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it)
+                if (rows.ok[it])
+                    a_ptr[it] = p.A2 + ((long)rows.y[it] * p.lda2 + (long)(kt - kt_second) * BK + lchunk * EPC) * sizeof(T);
+        };
         if (fast) {
             if (CONV) {
                 c0 = kc - lchunk * EPC;
@@ -617,6 +627,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
                     a_ptr[it] = rows.ok[it] ? p.A + (rows.off[it] + (long)kt0 * BK + lchunk * EPC) * sizeof(T) : zsrc;
                     a_step[it] = rows.ok[it] ? BK * (int)sizeof(T) : 0;
                 }
+                if (kt0 >= kt_second) second_operand(kt0);
             }
         }
 
@@ -625,6 +636,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
             char* sa = smem + stage * STAGE_BYTES + lds_wave;
             char* sw = sa + BM * 128;
             if (fast) {
+                if (!CONV && kt == kt_second) second_operand(kt);  // wave-uniform, once per run
 #pragma unroll
                 for (int it = 0; it < A_IT; ++it) {
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_ptr[it],
@@ -1154,6 +1166,11 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
         if (d->m % (d->hout * d->wout)) return DM_ERR_ARG;
     } else if (d->k % epc) {
         return DM_ERR_ARG;
+    } else if (d->a2) {
+        // dense second operand: whole k-tiles on both sides of the seam, no padded k tail
+        if (d->cin2 <= 0 || d->cin2 >= d->k || d->cin2 % bk || (d->k - d->cin2) % bk || d->k != d->kpad ||
+            d->lda2 % epc || !dm_aligned16(d->a2))
+            return DM_ERR_ARG;
     }
     if (d->epi < DM_EPI_PLAIN || d->epi > DM_EPI_QUICKGELU) return DM_ERR_ARG;
     if (d->epi == DM_EPI_GEGLU && (!d->bias || d->n % 64 || d->rowbias || d->r)) return DM_ERR_ARG;
@@ -1166,7 +1183,7 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     if (tile == DM_TILE_AUTO) dm_gemm_plan(d->dtype, d->m, d->n, d->k, d->epi, &tile, &splitk);
     int bm, bn;
     if (tile_dims(tile, &bm, &bn)) return DM_ERR_ARG;
-    if (d->conv && d->a2 && tile < DM_TILE_D128x128_S2) return DM_ERR_ARG;  // only the direct-to-LDS loop knows tap 9
+    if (d->a2 && tile < DM_TILE_D128x128_S2) return DM_ERR_ARG;  // only the direct-to-LDS loop reads a second operand
     // folded / produced LayerNorm statistics live in the epilogue: not with the separate split-K reduction
     if ((d->ln_in || d->ln_out) && splitk > 1) return DM_ERR_ARG;
     if (d->ln_in && (!d->ln_colsum || d->conv || !dm_aligned16(d->ln_colsum) || (reinterpret_cast<uintptr_t>(d->ln_in) & 7u)))
@@ -1207,7 +1224,7 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     a.M = d->m; a.N = d->n; a.K = d->k; a.Kpad = d->kpad;
     a.conv = d->conv; a.Hin = d->hin; a.Win = d->win; a.Hout = d->hout; a.Wout = d->wout;
     a.Cin = d->cin; a.stride = d->stride; a.up = d->up;
-    a.A2 = d->conv ? static_cast<const char*>(d->a2) : nullptr; a.lda2 = d->lda2; a.Cin2 = d->cin2;
+    a.A2 = static_cast<const char*>(d->a2); a.lda2 = d->lda2; a.Cin2 = d->cin2;
     a.epi = d->epi;
     a.splitk = splitk;
     a.partial = static_cast<float*>(d->workspace);

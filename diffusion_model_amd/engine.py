@@ -115,6 +115,7 @@ class Engine:
         self.fuse_ln = os.environ.get("DM_FUSE_LN", "1") == "1"
         self.tune_early = os.environ.get("DM_TUNE_EARLY", "1") != "0"
         self.fuse_skip = os.environ.get("DM_FUSE_SKIP", "1") != "0"  # residual_layer folded into the second conv
+        self.fuse_tail = os.environ.get("DM_FUSE_TAIL", "1") != "0"  # linear_geglu_2 + residue + conv_output as one GEMM
         self.fuse_gn_stats = os.environ.get("DM_FUSE_GN_STATS", "1") == "1"
         self.profile: Optional[dict] = None  # kernel class -> [events...] when profiling
         self._order_cache: Dict[Tuple[int, int, bool], torch.Tensor] = {}
@@ -244,6 +245,22 @@ class Engine:
         pw.ln_eps = float(ln.eps)
         return pw
 
+    def pack_chain(self, first: torch.nn.Linear, second: torch.nn.Conv2d) -> PackedWeight:
+        """Weights of ``second(first(a) + r)`` (a Linear, a residual add, a 1x1 convolution: all linear) as ONE
+        matrix over the concatenated row [a | r]: [W2 W1 | W2], bias W2 b1 + b2.  The product is formed in fp64."""
+        w1 = first.weight.detach().to(self.device, torch.float64)
+        w2 = second.weight.detach().to(self.device, torch.float64).reshape(second.out_channels, second.in_channels)
+        if w2.shape[1] != w1.shape[0] or w1.shape[1] % self.bk or w2.shape[1] % self.bk:
+            raise RuntimeError("chain needs matching widths that are whole k-tiles")
+        bias = torch.zeros(w2.shape[0], dtype=torch.float64, device=self.device)
+        if first.bias is not None:
+            bias = bias + w2 @ first.bias.detach().to(self.device, torch.float64)
+        if second.bias is not None:
+            bias = bias + second.bias.detach().to(self.device, torch.float64)
+        pw = self.pack_matrix(torch.cat([w2 @ w1, w2], dim=1).float(), bias.float())
+        pw.skip_cin = w2.shape[1]
+        return pw
+
     def pack_conv1x1(self, conv: torch.nn.Conv2d) -> PackedWeight:
         return self.pack_matrix(conv.weight.reshape(conv.out_channels, conv.in_channels), conv.bias)
 
@@ -275,7 +292,7 @@ class Engine:
              rowbias: Optional[torch.Tensor] = None, rows_per_batch: int = 0, residual: Optional[torch.Tensor] = None,
              conv: Optional[dict] = None, nchw_out: Optional[torch.Tensor] = None, persistent=False,
              gn_batch: int = 0, act: Optional[str] = None, ln_in: Optional[torch.Tensor] = None,
-             ln_out: bool = False) -> torch.Tensor:
+             ln_out: bool = False, a2: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``gn_batch`` > 0: a GroupNorm over ``gn_batch`` samples reads the output next; its statistics are
         accumulated by this launch where the chosen tile allows it.
         ``ln_out``: a LayerNorm folded into a later GEMM reads the output next; per-row sums are accumulated
@@ -298,7 +315,12 @@ class Engine:
             klass = "conv3x3"
         else:
             m = a.shape[0]
-            if a.shape[1] != pw.k:
+            if a2 is not None:
+                # the last pw.skip_cin columns of the logical A row live in a second tensor
+                if pw.skip_cin == 0 or a2.shape != (m, pw.skip_cin) or a.shape[1] + pw.skip_cin != pw.k:
+                    raise RuntimeError("second GEMM operand does not match the packed weights")
+                d.a2, d.lda2, d.cin2 = a2.data_ptr(), a2.stride(0), pw.skip_cin
+            elif a.shape[1] != pw.k:
                 raise RuntimeError(f"GEMM inner dimension mismatch: {a.shape[1]} vs {pw.k}")
             klass = "gemm"
         n_out = pw.n // 2 if pw.geglu else pw.n

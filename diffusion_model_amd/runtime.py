@@ -78,6 +78,7 @@ def pack_cross_attention(m, eng: Engine, ln=None) -> NS:
 
 def pack_attention_block(m, eng: Engine) -> NS:
     c = m.conv_input.in_channels
+    tail = eng.fuse_tail and c % eng.bk == 0
     return NS(kind="attn", c=c,
               gn_w=_f32(eng, m.group_norm.weight), gn_b=_f32(eng, m.group_norm.bias), gn_eps=m.group_norm.eps,
               conv_in=eng.pack_conv1x1(m.conv_input),
@@ -88,8 +89,11 @@ def pack_attention_block(m, eng: Engine) -> NS:
               ca=pack_cross_attention(m.attention_2, eng, ln=m.layer_norm_2 if eng.fuse_ln else None),
               ln3_w=_f32(eng, m.layer_norm_3.weight), ln3_b=_f32(eng, m.layer_norm_3.bias), ln3_eps=m.layer_norm_3.eps,
               geglu1=eng.pack_linear(m.linear_geglu_1, geglu=True, ln=m.layer_norm_3 if eng.fuse_ln else None),
-              geglu2=eng.pack_linear(m.linear_geglu_2),
-              conv_out=eng.pack_conv1x1(m.conv_output))
+              geglu2=None if tail else eng.pack_linear(m.linear_geglu_2),
+              conv_out=None if tail else eng.pack_conv1x1(m.conv_output),
+              # linear_geglu_2 -> += residue -> conv_output has no non-linearity in between: one GEMM over the row
+              # [gelu product | residue] with pre-multiplied weights
+              tail=eng.pack_chain(m.linear_geglu_2, m.conv_output) if tail else None)
 
 
 def pack_conv_layer(conv: torch.nn.Conv2d, eng: Engine, up: bool = False) -> NS:
@@ -227,8 +231,11 @@ def run_attention_block(eng: Engine, pk: NS, x, batch: int, h: int, w: int, kv, 
         t = run_cross_attention(eng, pk.ca, a, kv, batch, s, sk, residual=t)
         a = eng.layernorm(t, pk.ln3_w, pk.ln3_b, pk.ln3_eps)
         a = eng.gemm(a, pk.geglu1)
-    t = eng.gemm(a, pk.geglu2, residual=t)
-    eng.gemm(t, pk.conv_out, out=out, residual=x, gn_batch=batch)
+    if pk.tail is not None:
+        eng.gemm(a, pk.tail, a2=t, out=out, residual=x, gn_batch=batch)
+    else:
+        t = eng.gemm(a, pk.geglu2, residual=t)
+        eng.gemm(t, pk.conv_out, out=out, residual=x, gn_batch=batch)
     eng.arena.release(mark)
     return out
 

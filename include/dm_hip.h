@@ -114,10 +114,14 @@ typedef struct DmGemmDesc {
     const float* ln_colsum;
     float ln_eps;
     double* ln_out;
-    /* conv only: a pointwise (1x1) term over a second tensor appended to the k axis, k = 9*cin + cin2:
-     * out[m] += sum_c a2[m][c] * w[n][9*cin + c].  Folds ResidualBlock's residual_layer (blocks.py:42,70-72)
-     * into its second convolution.  Stride-1, same-size convolutions; cin and cin2 multiples of the k-tile
-     * (32 fp32 / 64 bf16); direct-to-LDS tiles.  NULL = none. */
+    /* Second operand appended to the k axis (NULL = none); direct-to-LDS tiles only; cin2 and k - cin2 (conv: cin)
+     * multiples of the k-tile (32 fp32 / 64 bf16).
+     * conv: a pointwise (1x1) term over a second tensor, k = 9*cin + cin2:
+     *   out[m] += sum_c a2[m][c] * w[n][9*cin + c]  (stride-1, same-size convolutions).  Folds ResidualBlock's
+     *   residual_layer (blocks.py:42,70-72) into its second convolution.
+     * dense: columns k - cin2 .. k - 1 of the A row come from a2[m][0 .. cin2) instead of a (k == kpad).  Lets
+     *   AttentionBlock's linear_geglu_2 -> += residue -> conv_output chain (blocks.py:152-159) run as one GEMM
+     *   over [gelu product | residue] with pre-multiplied weights. */
     const void* a2;
     long lda2;
     int cin2;

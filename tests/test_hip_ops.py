@@ -217,6 +217,30 @@ def test_gemm_geglu(eng):
     assert max_rel(out.float(), v * F.gelu(g)) < tol(eng.dtype)
 
 
+@pytest.mark.parametrize("tile,sk", [(_lib.TILE_AUTO, 1)] + [(t, sk) for t in DMA_TILES for sk in (1, -19)])
+def test_gemm_second_operand_and_chain(eng, tile, sk):
+    """second(first(a) + r) + x as one GEMM over the row [a | r] (linear_geglu_2 -> += residue -> conv_output):
+    the k axis is read from two tensors, the seam on a k-tile boundary; work-list splits cross it."""
+    m, c = 200, 128
+    a = tin("ch.a", (m, 4 * c)); r = tin("ch.r", (m, c)); x = tin("ch.x", (m, c))
+    first = torch.nn.Linear(4 * c, c); second = torch.nn.Conv2d(c, c, 1)
+    with torch.no_grad():
+        first.weight.copy_(tin("ch.w1", (c, 4 * c), scale=1 / math.sqrt(4 * c))); first.bias.copy_(tin("ch.b1", (c,)))
+        second.weight.copy_(tin("ch.w2", (c, c, 1, 1), scale=1 / math.sqrt(c))); second.bias.copy_(tin("ch.b2", (c,)))
+    pw = eng.pack_chain(first, second)
+    assert pw.k == 5 * c and pw.skip_cin == c
+    w2 = second.weight.detach().reshape(c, c).double()
+    ref = ((rnd(a, eng.dtype).double() @ first.weight.detach().double().T + first.bias.detach().double()
+            + rnd(r, eng.dtype).double()) @ w2.T + second.bias.detach().double() + rnd(x, eng.dtype).double())
+    dev = eng.device
+    eng.tile_override = None if tile == _lib.TILE_AUTO else (tile, sk)
+    out = eng.gemm(a.to(dev).to(eng.dtype), pw, a2=r.to(dev).to(eng.dtype), residual=x.to(dev).to(eng.dtype))
+    eng.tile_override = None
+    assert max_rel(out.float(), ref) < tol(eng.dtype)
+    with pytest.raises(RuntimeError):  # weights packed for two operands need both
+        eng.gemm(a.to(dev).to(eng.dtype), pw)
+
+
 @pytest.mark.parametrize("cin,cout,h,w,stride,upx", [(320, 320, 8, 8, 1, 0), (64, 128, 9, 7, 1, 0), (320, 320, 16, 16, 2, 0),
                                                       (64, 64, 7, 10, 2, 0), (128, 64, 6, 5, 1, 1), (4, 320, 8, 8, 1, 0)])
 def test_conv3x3(eng, cin, cout, h, w, stride, upx):
