@@ -107,6 +107,10 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"HIP extension not built: {LIB_PATH} is missing. Run `python build.py` (needs hipcc); "
                 "diffusion_model_amd has no CPU or PyTorch fallback.")
+        # PyTorch ships its own HIP runtime (torch/lib/libamdhip64.so); it must be the one already mapped when this
+        # library's dependency on libamdhip64 is resolved, or the process ends up with the system runtime serving
+        # this library and a device it cannot see (hipErrorNoDevice at the first launch).
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(handle, name)

@@ -7,6 +7,7 @@
 //   * two storage types: float (fp32 mode, exact f32 MFMA) and bf16 (bf16 mode, f32 accumulate)
 //   * a "chunk" is 16 bytes of the contraction dimension: 4 floats or 8 bf16
 #pragma once
+#include <cstdio>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -126,8 +127,13 @@ __device__ __forceinline__ u32x4 ldg16(const void* p, bool pred) {
     return pred ? *reinterpret_cast<const u32x4*>(p) : z;
 }
 
+// Status of the launch just made.  hipGetLastError also returns (and clears) what EARLIER runtime calls of this
+// host thread left behind; hipErrorNotReady from an event / stream query by the caller's framework is such a
+// leftover and never the result of a launch.  Any other code is reported with its name on stderr.
 static inline int dm_check_launch() {
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? DM_OK : DM_ERR_LAUNCH;
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess || e == hipErrorNotReady) return DM_OK;
+    fprintf(stderr, "libdm_hip: %s (%s)\n", hipGetErrorName(e), hipGetErrorString(e));
+    return DM_ERR_LAUNCH;
 }
 static inline bool dm_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

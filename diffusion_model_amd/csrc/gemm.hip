@@ -955,9 +955,12 @@ struct TileInfo {
 
 template <typename K> int launch_kernel(K kfn, bool& attr_done, const TileInfo& t, const GemmArgs& a, hipStream_t stream) {
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, t.lds) !=
-            hipSuccess)
+        const hipError_t e =
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, t.lds);
+        if (e != hipSuccess) {
+            fprintf(stderr, "libdm_hip: hipFuncSetAttribute(%d bytes of LDS): %s\n", t.lds, hipGetErrorName(e));
             return DM_ERR_LAUNCH;
+        }
         attr_done = true;
     }
     const int ntm = (a.M + t.bm - 1) / t.bm, ntn = (a.N + t.bn - 1) / t.bn;
