@@ -114,7 +114,7 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % max(torch.cuda.device_count(), 1))  # ranks share GPUs only in rehearsals
     torch.cuda.set_device(device)
 
     B, HW, T = cfg["batch"], cfg["latent"], args.ddpm_steps
