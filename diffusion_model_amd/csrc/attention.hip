@@ -69,8 +69,14 @@ template <int OFF0, int OFF1> __device__ __forceinline__ void tr_read_pair(u32x2
                  : "v"(lds_addr), "i"(OFF0), "i"(OFF1));
 }
 
-template <typename T, int D, int QT>
+// DSPLIT (problems with fewer query tiles than CUs): the four waves of a block share ONE tile of 16 query rows and
+// split the head dimension instead.  Each wave multiplies every fourth k-step of K Q^T, the partial score tiles are
+// summed through LDS (two small buffers, alternating per key tile), every wave forms the same probabilities and
+// multiplies them with every fourth 16-column tile of V.  Four times the blocks, a quarter of the MFMA chain per
+// wave and key tile: the deep U-Net levels at batch 1 are bound by that chain, not by throughput.
+template <typename T, int D, int QT, bool DSPLIT = false>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
+    static_assert(!DSPLIT || QT == 1, "the head-dimension split works on one query tile per block");
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int ESZ = sizeof(T);
     constexpr int NKS = (D * ESZ + 63) / 64;   // 64-byte k-steps over the head dim
@@ -94,7 +100,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     constexpr int VP = (V_PIECES + 3) / 4;
     // When D leaves spare rows in the last 16-row tile of O^T, column D of the V tile is fed with ones so
     // that the second product also delivers sum_k P[q][k] (in O^T row D) and the VALU never adds the row sum.
-    constexpr bool ONES = (D % 16) != 0;
+    constexpr bool ONES = !DSPLIT && (D % 16) != 0;
+    constexpr int PBUF = 4 * NKT * 64 * 16;  // DSPLIT: one buffer of partial score tiles (4 waves x NKT x 64 lanes x 16 B)
     auto ksw = [](int row) { return (row >> 1) & 3; };
     static_assert(D % EPC == 0, "head dim must be a whole number of 16-byte chunks");
 
@@ -112,7 +119,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     }
     const int bh = logical / p.nqblk;
     const int h = bh % p.heads, b = bh / p.heads;
-    const int q0 = (logical - bh * p.nqblk) * (64 * QT) + wave * (16 * QT);
+    const int q0 = DSPLIT ? (logical - bh * p.nqblk) * 16 : (logical - bh * p.nqblk) * (64 * QT) + wave * (16 * QT);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);  // scalar copy for wave-uniform branches
     const char* zsrc = reinterpret_cast<const char*>(g_attn_zero16);
 
     // ---- loader coordinates (fixed over the key loop)
@@ -220,11 +228,6 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 
         // ---- S^T - m_ref = K Q^T - m_ref  (log2 units); K fragments are fetched one k-step ahead
         f32x4 sacc[NKT][QT];
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) sacc[kt][qt] = f32x4{-m_ref[qt], -m_ref[qt], -m_ref[qt], -m_ref[qt]};
-        u32x4 kf[2][NKT];
         auto load_k = [&](int ks, u32x4 (&dst)[NKT]) {
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
@@ -232,14 +235,46 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                 dst[kt] = *reinterpret_cast<const u32x4*>(s_k + ks * K_SLAB + row * 64 + ((qp ^ ksw(row)) << 4));
             }
         };
-        load_k(0, kf[0]);
+        if constexpr (DSPLIT) {
+            const float start = wv == 0 ? -m_ref[0] : 0.f;  // the shift is added once, by wave 0's partial
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            if (ks + 1 < NKS) load_k(ks + 1, kf[(ks + 1) & 1]);
+            for (int kt = 0; kt < NKT; ++kt) sacc[kt][0] = f32x4{start, start, start, start};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                if ((ks & 3) == wv) {
+                    u32x4 kfs[NKT];
+                    load_k(ks, kfs);
+#pragma unroll
+                    for (int kt = 0; kt < NKT; ++kt) Mma16<T>::mma(sacc[kt][0], kfs[kt], qf[0][ks]);
+                }
+            }
+            f32x4* part = reinterpret_cast<f32x4*>(smem + 2 * STAGE + (t & 1) * PBUF);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) part[(wv * NKT + kt) * 64 + lane] = sacc[kt][0];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                f32x4 sum = part[kt * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) sum += part[(w * NKT + kt) * 64 + lane];
+                sacc[kt][0] = sum;
+            }
+        } else {
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt) Mma16<T>::mma(sacc[kt][qt], kf[ks & 1][kt], qf[qt][ks]);
+                for (int qt = 0; qt < QT; ++qt) sacc[kt][qt] = f32x4{-m_ref[qt], -m_ref[qt], -m_ref[qt], -m_ref[qt]};
+            u32x4 kf[2][NKT];
+            load_k(0, kf[0]);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (ks + 1 < NKS) load_k(ks + 1, kf[(ks + 1) & 1]);
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) Mma16<T>::mma(sacc[kt][qt], kf[ks & 1][kt], qf[qt][ks]);
+            }
         }
         // ---- softmax numerators; lane holds keys t*KT + key_of(kt, 4*qp + r) of query row c
         // Masks, only on the tiles that need them (wave-uniform test): keys past the end of the sequence
@@ -306,7 +341,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                 u32x2 vlo[DT], vhi[DT];
                 static_for<0, DT>([&](auto dt_) {
                     constexpr int dt = decltype(dt_)::value;
-                    tr_read_pair<kk * 32 * VPITCH + dt * 32, (kk * 32 + 16) * VPITCH + dt * 32>(vlo[dt], vhi[dt], v_addr);
+                    if (!DSPLIT || (dt & 3) == wv)
+                        tr_read_pair<kk * 32 * VPITCH + dt * 32, (kk * 32 + 16) * VPITCH + dt * 32>(vlo[dt], vhi[dt], v_addr);
                 });
                 u32x4 pb[QT];
 #pragma unroll
@@ -319,6 +355,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
+                    if (DSPLIT && (dt & 3) != wv) continue;
                     const u32x4 va = u32x4{vlo[dt][0], vlo[dt][1], vhi[dt][0], vhi[dt][1]};
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) Mma16<T>::mma(oacc[dt][qt], va, pb[qt]);
@@ -329,6 +366,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
             for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
+                    if (DSPLIT && (dt & 3) != wv) continue;
                     // keys 16*kt + 4*qp + e, e = 0..3, of column dt*16 + c: the e-th f32 MFMA of the chunk
                     u32x4 va;
 #pragma unroll
@@ -365,7 +403,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int d0 = dt * 16 + 4 * qp;
-            if (d0 >= D) continue;
+            if (d0 >= D || (DSPLIT && (dt & 3) != wv)) continue;
             const f32x4 v = oacc[dt][qt] * inv;
             if constexpr (sizeof(T) == 4) {
                 *reinterpret_cast<f32x4*>(orow + d0) = v;
@@ -376,14 +414,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     }
 }
 
-template <typename T, int D, int QT> int attn_launch_qt(const AttnArgs& a, int batch, hipStream_t s) {
+template <typename T, int D, int QT, bool DSPLIT = false> int attn_launch_qt(const AttnArgs& a, int batch, hipStream_t s) {
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int NKS = (D * (int)sizeof(T) + 63) / 64, DT = (D + 15) / 16, KT = 8 * EPC;
     constexpr int VCH0 = DT * 16 / EPC;  // V image: see the kernel
     constexpr int VCH = sizeof(T) == 4 ? (VCH0 | 1) : VCH0 + (6 - VCH0 % 4) % 4;
-    constexpr int LDS = 2 * (NKS * KT * 64 + (KT * VCH * 16 + 1023) / 1024 * 1024);
+    constexpr int LDS = 2 * (NKS * KT * 64 + (KT * VCH * 16 + 1023) / 1024 * 1024) + (DSPLIT ? 2 * 4 * (KT / 16) * 64 * 16 : 0);
     static bool attr_done = false;
-    auto kfn = attn_kernel<T, D, QT>;
+    auto kfn = attn_kernel<T, D, QT, DSPLIT>;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
             hipSuccess)
@@ -391,7 +429,7 @@ template <typename T, int D, int QT> int attn_launch_qt(const AttnArgs& a, int b
         attr_done = true;
     }
     AttnArgs args = a;
-    args.nqblk = (a.sq + 64 * QT - 1) / (64 * QT);
+    args.nqblk = DSPLIT ? (a.sq + 15) / 16 : (a.sq + 64 * QT - 1) / (64 * QT);
     const long nblk = (long)args.nqblk * a.heads * batch;
     if (nblk > 0x7fffffffL) return DM_ERR_ARG;
     args.nblk = (int)nblk;
@@ -410,7 +448,13 @@ template <typename T, int D> int attn_launch(const AttnArgs& a, int batch, hipSt
     }
     // Measured on MI355X (bf16 batch 16 and fp32 batch 1, all four U-Net levels): 16 rows per wave wins
     // everywhere; the extra waves per SIMD hide the softmax VALU work better than wider tiles reuse K.
-    (void)per64;
+    // Far fewer 64-row blocks than CUs and a long MFMA chain per key tile (fp32, wide heads): split the head
+    // dimension over the waves instead (16 rows per block).  Measured at batch 1 fp32: d = 160, S = 256: 32.8 -> 23.1 us
+    // (77 keys: 16.9 -> 13.0 us); d <= 80 and every bf16 shape are faster unsplit.
+    if constexpr (sizeof(T) == 4 && D >= 160) {
+        static const int dsplit = getenv("DM_ATTN_DSPLIT") ? atoi(getenv("DM_ATTN_DSPLIT")) : -1;  // tuning knob: 0 / 1 force
+        if (dsplit == 1 || (dsplit < 0 && per64 < 128)) return attn_launch_qt<T, D, 1, true>(a, batch, s);
+    }
     return attn_launch_qt<T, D, 1>(a, batch, s);
 }
 
