@@ -199,10 +199,19 @@ class Engine:
                 if r["base"] == p:
                     rec = r
                     break
-        if (rec is None or not rec["valid"] or rec["ld"] != x.stride(0) or rec["cols"] != x.shape[1]
+        if rec is None:
+            # a channel slice of a shared buffer (an encoder output that lives inside a decoder's concat buffer):
+            # usable when one producer accumulated exactly that slice
+            for r in self._gn_shared:
+                off = (p - r["base"]) // self.esz
+                if (r["valid"] and r["ld"] == x.stride(0) and r["rows"] == x.shape[0] and r["batch"] == batch
+                        and r["base"] < p < r["base"] + r["ld"] * self.esz and (off, x.shape[1]) in r.get("ranges", ())):
+                    return dict(stats_ptr=r["stats"].data_ptr() + off * 8, ld=r["cols"])
+            return None
+        if (not rec["valid"] or rec["ld"] != x.stride(0) or rec["cols"] != x.shape[1]
                 or rec["rows"] != x.shape[0] or rec["batch"] != batch or rec["parts"] != rec["cols"]):
             return None
-        return rec
+        return dict(stats_ptr=rec["stats"].data_ptr(), ld=rec["cols"])
 
     # ------------------------------------------------------------------ weight packing
     def _order(self, n: int, npad: int, geglu: bool) -> torch.Tensor:
@@ -387,6 +396,7 @@ class Engine:
                 d.ld_stats = rec["cols"]
                 d.rows_per_batch = hw
                 rec["parts"] += pw.n
+                rec.setdefault("ranges", []).append((ch_off, n_out))
             else:
                 rec["valid"] = False
         with self._prof(klass, 2.0 * m * pw.n * (pw.k if conv is None else 9 * conv["cin_real"] + pw.skip_cin),
@@ -521,7 +531,7 @@ class Engine:
             self._gn_auto.pop(x.data_ptr(), None)
             with self._prof("groupnorm", float(batch * hw * c * self.esz * 2), f"b={batch} hw={hw} c={c} fused-stats"):
                 check(self.lib.dm_groupnorm_apply_sums(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), batch,
-                                                       hw, c, groups, self.dm, rec["stats"].data_ptr(), c,
+                                                       hw, c, groups, self.dm, rec["stats_ptr"], rec["ld"],
                                                        gamma.data_ptr(), beta.data_ptr(), eps, int(silu), self.stream),
                       "groupnorm_apply_sums")
             return out
