@@ -65,11 +65,46 @@ class DDIMScheduler(BaseScheduler):
         if device.type != "cuda":
             raise RuntimeError("DDIMScheduler.sample: device must be the HIP device ('cuda'); there is no CPU path")
         sample = draw_normal(shape, generator, device)
+        from ..models.diffusion import Diffusion
+        if isinstance(model, Diffusion) and context is not None:
+            # the model never touches the generator, so the per-step draws can all be made up front
+            noises = [draw_normal(shape, generator, device) for _ in self.timesteps] if self.eta > 0 else []
+            return self.sample_from_noise(model, sample, noises, context)
         for t in self.timesteps.tolist():
             time_emb = self._get_timestep_embedding(torch.tensor([t] * shape[0]), 320).to(device)
             noise_pred = model(sample, context, time_emb) if context is not None else model(sample, time_emb)
             sample = self.step(noise_pred, t, sample, generator=generator)
         return sample
+
+    def step_coefficients(self) -> torch.Tensor:
+        """(n, 5) fp32 CPU table in loop order, row s = the scalars ``step`` forms for ``timesteps[s]``:
+        [sqrt(1-a_t), sqrt(a_t), sqrt(a_prev), sqrt(1-a_prev), eta*sqrt(variance)]."""
+        ratio = self.num_train_timesteps // self.num_inference_steps
+        rows = []
+        for t in self.timesteps.tolist():
+            a_t, a_p = self._alpha_pair(t, t - ratio)
+            std = (self.eta * self._get_variance(t, t - ratio).sqrt()) if self.eta > 0 else torch.tensor(0.0)
+            rows.append(torch.stack([(1 - a_t).sqrt(), a_t.sqrt(), a_p.sqrt(), (1 - a_p).sqrt(),
+                                     torch.as_tensor(std, dtype=torch.float32)]).to(torch.float32))
+        return torch.stack(rows)
+
+    @torch.no_grad()
+    def sample_from_noise(self, model, x_T: torch.Tensor, noises, context: torch.Tensor, trace=None) -> torch.Tensor:
+        """Reverse loop on the HIP engine as a captured step graph (same machinery as DDPMScheduler's):
+        ``noises[s]`` is injected at loop step s when eta > 0 (pass an empty list for eta = 0)."""
+        from .ddpm_scheduler import StepLoop
+        require_hip(x_T, "DDIMScheduler.sample_from_noise")
+        eng, _ = model.hip_pack(x_T.device)
+        key = (id(model), tuple(x_T.shape), str(x_T.device), id(eng), context.shape[1], self.num_inference_steps,
+               float(self.eta), bool(self.clip_sample))
+        if getattr(self, "_loop_key", None) != key:
+            self._loop = StepLoop(model, tuple(x_T.shape), x_T.device, context.shape[1], timesteps=self.timesteps.tolist(),
+                                  coef=self.step_coefficients(), step="dm_ddim_step", clip=self.clip_sample,
+                                  n_noise=len(self.timesteps) if self.eta > 0 else 0)
+            self._loop_key = key
+        return self._loop.run(self, model, x_T, list(noises), context, trace)
+
+    use_hip_graph = True
 
     def _get_timestep_embedding(self, timesteps: torch.Tensor, embedding_dim: int, max_period: int = 10000):
         if timesteps.device.type != "cuda":

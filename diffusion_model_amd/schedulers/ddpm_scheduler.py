@@ -116,7 +116,10 @@ class DDPMScheduler(BaseScheduler):
         st = self._loops.get(key)
         if st is None:
             self._loops.clear()  # one resident loop state at a time
-            st = _DdpmLoop(self, model, shape, device, sk)
+            T = self.num_train_timesteps
+            st = StepLoop(model, shape, device, sk, timesteps=list(range(T - 1, -1, -1)),
+                          coef=self.step_coefficients().flip(0), step="dm_ddpm_step", clip=self.clip_sample,
+                          n_noise=T - 1)
             self._loops[key] = st
         return st
 
@@ -135,14 +138,21 @@ class DDPMScheduler(BaseScheduler):
                 f"beta_range=[{self.beta_start:.6f}, {self.beta_end:.6f}])")
 
 
-class _DdpmLoop:
-    """Persistent device state of one (model, latent shape) sampling loop and its captured step graph."""
+class StepLoop:
+    """Persistent device state of one (model, latent shape) sampling loop and its captured step graph.
 
-    def __init__(self, sched: DDPMScheduler, model, shape, device, sk):
+    The loop is described by tables in loop order: ``timesteps[s]`` (the model's time input at step s), ``coef[s]``
+    (the five scalars of the fused update kernel named by ``step``) and ``n_noise`` pre-drawn noise tensors
+    (step s adds ``noises[s]`` when its noise coefficient is non-zero).  DDPM and DDIM differ only in these.
+    """
+
+    def __init__(self, model, shape, device, sk, timesteps, coef: torch.Tensor, step: str, clip: bool, n_noise: int):
         self.lib = _lib.lib()
+        self.step_fn = getattr(self.lib, step)
         self.shape, self.device = shape, device
-        T = sched.num_train_timesteps
+        T = len(timesteps)
         self.T = T
+        self.n_noise = n_noise
         self.eng, self.pk = model.hip_pack(device)
         self.eng.autotune = True  # first (eager) step times tile/split-K candidates per GEMM shape
         self.sig = rt._signature(model)
@@ -150,12 +160,11 @@ class _DdpmLoop:
         self.x = torch.empty(shape, **f32)
         self.eps = torch.empty(shape, **f32)
         self.time_in = torch.empty(shape[0], 320, **f32)
-        self.noise = torch.empty((max(T - 1, 1),) + tuple(shape), **f32)
+        self.noise = torch.empty((max(n_noise, 1),) + tuple(shape), **f32)
         self.counter = torch.zeros(1, dtype=torch.int32, device=device)
-        # tables in loop order: row s <-> timestep T-1-s
-        self.coef = sched.step_coefficients().flip(0).contiguous().to(device)
-        self.temb = sinusoidal_table(torch.arange(T - 1, -1, -1), 320).contiguous().to(device)
-        self.clip = int(sched.clip_sample)
+        self.coef = coef.to(torch.float32).contiguous().to(device)
+        self.temb = sinusoidal_table(torch.tensor(list(timesteps), dtype=torch.long), 320).contiguous().to(device)
+        self.clip = int(clip)
         self.stream = torch.cuda.Stream(device)
         self.kvs = None
         self.sk = sk
@@ -181,9 +190,9 @@ class _DdpmLoop:
         self.eng.reset()
         rt.diffusion_forward_into(self.eng, self.pk, self.x, None, self.kvs, self.sk, self.eps,
                                   tproj=self.tproj_row.expand(B, n))
-        check(self.lib.dm_ddpm_step(self.x.data_ptr(), self.eps.data_ptr(), self.noise.data_ptr(), self.x.data_ptr(),
-                                    self.x.numel(), self.coef.data_ptr(), self.counter.data_ptr(), self.clip, s),
-              "ddpm_step")
+        check(self.step_fn(self.x.data_ptr(), self.eps.data_ptr(), self.noise.data_ptr() if self.n_noise else None,
+                           self.x.data_ptr(), self.x.numel(), self.coef.data_ptr(), self.counter.data_ptr(), self.clip, s),
+              "reverse step")
         check(self.lib.dm_advance_counter(self.counter.data_ptr(), 1, s), "advance_counter")
 
     def run(self, sched, model, x_T, noises, context, trace):
@@ -197,6 +206,8 @@ class _DdpmLoop:
         self.stream.wait_stream(caller)
         with torch.cuda.stream(self.stream):
             self.x.copy_(x_T.to(torch.float32))
+            if len(noises) != self.n_noise:
+                raise RuntimeError(f"expected {self.n_noise} noise tensors, got {len(noises)}")
             for i, nz in enumerate(noises):
                 self.noise[i].copy_(nz)
             self.counter.zero_()

@@ -341,14 +341,22 @@ def test_cfg_denoise_loop_matches_oracle(model_f32, dev):
 
 
 def test_ddim_sample_matches_oracle(model_f32, dev):
-    T, n = 1000, 2
+    """DDIM sampling through the captured step graph (and eagerly), deterministic and with eta > 0, against the
+    oracle's loop with the same draws: x_T first, then one draw per step (the reference's generator order)."""
+    T, n = 1000, 3
     state = {k: v.cpu() for k, v in model_f32.state_dict().items()}
     ctx = torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(2))
-    d = DDIMScheduler(num_train_timesteps=T, num_inference_steps=n)
-    got = d.sample(model_f32, (1, 4, 16, 16), ctx.to(dev), torch.Generator().manual_seed(9), dev)
-    x = torch.randn((1, 4, 16, 16), generator=torch.Generator().manual_seed(9))
     tab = sched_ref.make_tables(T)
-    for t in sched_ref.ddim_timesteps(T, n).tolist():
-        eps = unet_ref.diffusion(state, x, ctx, sched_ref.timestep_embedding(torch.tensor([t]), 320))
-        x = sched_ref.ddim_step(tab, eps, t, x, T, n)
-    assert max_rel(got, x) < 1e-3
+    for eta in (0.0, 0.5):
+        gen = torch.Generator().manual_seed(9)
+        x = torch.randn((1, 4, 16, 16), generator=gen)
+        steps = sched_ref.ddim_timesteps(T, n).tolist()  # 4 of them: flip(arange(0, 1000, 333)), as the reference
+        noises = [torch.randn((1, 4, 16, 16), generator=gen) for _ in steps] if eta > 0 else [None] * len(steps)
+        for i, t in enumerate(steps):
+            eps = unet_ref.diffusion(state, x, ctx, sched_ref.timestep_embedding(torch.tensor([t]), 320))
+            x = sched_ref.ddim_step(tab, eps, t, x, T, n, eta, noises[i])
+        d = DDIMScheduler(num_train_timesteps=T, num_inference_steps=n, eta=eta)
+        for use_graph in (False, True, True):  # eager, capture + replay, replay of the cached graph
+            d.use_hip_graph = use_graph
+            got = d.sample(model_f32, (1, 4, 16, 16), ctx.to(dev), torch.Generator().manual_seed(9), dev)
+            assert max_rel(got, x) < F32, (eta, use_graph)
