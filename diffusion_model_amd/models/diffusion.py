@@ -1,4 +1,6 @@
 """Noise predictor eps(x_t, context, t) (reference: src/models/diffusion.py:15-101)."""
+import weakref
+
 import torch
 from torch import nn
 
@@ -52,8 +54,21 @@ class Diffusion(nn.Module):
         eng = engine_for(self, latent)
         pk = rt.cached_pack(self, eng, rt.pack_diffusion)
         eng.reset()
-        kvs, sk = rt.precompute_context(eng, pk.unet, context)
+        kvs, sk = self._context_kv(eng, pk, context)
         out = torch.empty(latent.shape[0], pk.final.cout, latent.shape[2], latent.shape[3], dtype=torch.float32,
                           device=latent.device)
         rt.diffusion_forward_into(eng, pk, latent.float().contiguous(), time.float().contiguous(), kvs, sk, out)
         return out.to(latent.dtype)
+
+    def _context_kv(self, eng, pk, context: torch.Tensor):
+        """Cross-attention K / V of all 16 AttentionBlocks for ``context``.  They depend on neither the latent nor
+        the timestep, so a loop that passes the SAME tensor object every step (and has not written to it: torch's
+        version counter) gets them from the previous call instead of 32 projection launches."""
+        c = self.__dict__.get("_dm_ctx_cache")
+        key = (id(eng), id(pk), context._version, tuple(context.shape), context.dtype, context.data_ptr())
+        if c is not None and c["ref"]() is context and c["key"] == key:
+            return c["kvs"], context.shape[1]
+        reuse = c["kvs"] if c is not None and c["key"][:2] == key[:2] and c["key"][3] == key[3] else None
+        kvs, sk = rt.precompute_context(eng, pk.unet, context, persistent=reuse is None, out=reuse)
+        self.__dict__["_dm_ctx_cache"] = dict(ref=weakref.ref(context), key=key, kvs=kvs)
+        return kvs, sk

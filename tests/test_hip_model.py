@@ -214,6 +214,25 @@ def test_oracle_parity_fresh_inputs(model_f32, dev):
     assert max_rel(out, ref) < F32
 
 
+def test_context_projection_cache_follows_the_tensor(model_f32, dev):
+    """The K / V projections of the conditioning are kept between calls only while the caller passes the same,
+    unmodified tensor object: an in-place write or another tensor must give that tensor's result."""
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn(1, 4, 16, 16, generator=gen).to(dev)
+    temb = sched_ref.timestep_embedding(torch.tensor([300]), 320).to(dev)
+    ctx = torch.randn(1, 77, 768, generator=gen).to(dev)
+    first = model_f32(x, ctx, temb)
+    assert torch.equal(model_f32(x, ctx, temb), first)                 # served from the kept projections
+    assert torch.equal(model_f32(x, ctx.clone(), temb), first)         # same values in another tensor
+    other = torch.randn(1, 77, 768, generator=gen).to(dev)
+    want = model_f32(x, other, temb)
+    assert not torch.equal(want, first)
+    ctx.copy_(other)                                                   # in-place write to the cached tensor
+    assert torch.equal(model_f32(x, ctx, temb), want)
+    two = model_f32(x.repeat(2, 1, 1, 1), torch.cat([other, ctx]), temb.repeat(2, 1))  # other batch size: new buffers
+    assert max_rel(two[0:1], want) < 1e-5 and max_rel(two[1:2], want) < 1e-5
+
+
 def test_linearity_free_properties_full_size(model_f32, dev):
     """Size-independent checks at 64x64 (the benchmark size): batch members are independent and the
     result does not depend on how a batch is split (what data-parallel sharding relies on)."""
