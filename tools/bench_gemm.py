@@ -21,6 +21,7 @@ ap.add_argument("--tiles", default="1,11,12,13")
 ap.add_argument("--sk", default="1")
 ap.add_argument("--shapes", default="all")
 ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--plain", action="store_true", help="pack the wide layers without the GEGLU epilogue")
 ap.add_argument("--apad", type=int, default=0, help="extra elements in the row stride of A (channel-interleave experiments)")
 args = ap.parse_args()
 
@@ -69,7 +70,7 @@ def run(kind, cin, cout, hw):
         else:
             m = B * hw * hw
         lin = torch.nn.Linear(cin, cout).to(dev)
-        geglu = cout >= 8 * cin
+        geglu = cout >= 8 * cin and not args.plain
         pw = eng.pack_linear(lin, geglu=geglu)
         a = (torch.randn(m, cin + args.apad, device=dev, generator=gen)).to(dt)[:, :cin]
         geom = None
