@@ -22,6 +22,7 @@ ap.add_argument("--sk", default="1")
 ap.add_argument("--shapes", default="all")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--plain", action="store_true", help="pack the wide layers without the GEGLU epilogue")
+ap.add_argument("--ldc0", action="store_true", help="every output row lands on row 0 (store issue cost without the DRAM traffic)")
 ap.add_argument("--apad", type=int, default=0, help="extra elements in the row stride of A (channel-interleave experiments)")
 args = ap.parse_args()
 
@@ -77,6 +78,8 @@ def run(kind, cin, cout, hw):
         flops = 2.0 * m * cout * cin
         label = f"gemm k={cin:4d} n={cout:5d} m={m}" + (" geglu" if geglu else "")
     out = torch.empty(m, pw.n // 2 if pw.geglu else pw.n, dtype=dt, device=dev)
+    if args.ldc0:
+        out = out[:1].expand(m, out.shape[1])
     res = []
     for t in tiles:
         for sk in sks:
