@@ -73,6 +73,7 @@ _PROTOS = {
     "dm_attention": (C.c_int, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dm_embed_tokens": (C.c_int, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp]),
     "dm_rescale": (C.c_int, [_vp, _vp, _l, _i, _f, _f, _f, _f, _i, _f, _f, _vp]),
+    "dm_u8_to_images": (C.c_int, [_vp, _i, _i, _l, _f, _f, _f, _f, _vp, _i, _vp]),
     "dm_images_to_u8": (C.c_int, [_vp, _i, _i, _i, _l, _f, _f, _f, _f, _f, _f, _vp, _vp]),
     "dm_linear_rows": (C.c_int, [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "dm_timestep_embedding": (C.c_int, [_vp, _i, _i, _f, _vp, _vp]),
@@ -116,7 +117,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dm_abi_version() != 4:
+        if handle.dm_abi_version() != 5:
             raise RuntimeError("libdm_hip.so ABI version mismatch; rebuild with `python build.py`")
         _lib = handle
     return _lib

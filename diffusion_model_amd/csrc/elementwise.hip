@@ -271,6 +271,19 @@ __global__ __launch_bounds__(EW_THREADS) void images_to_u8_rgb4_kernel(const flo
     }
 }
 
+// (H, W, C) or (B, H, W, C) uint8 pixels -> rescaled floating-point planes (B, C, H, W): the tensor conversion,
+// rescale and move_channel(to="first") of prepare_image_tensor (scripts/utils.py:203-212) in one pass.
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void u8_to_images_kernel(const unsigned char* __restrict__ x, int c, long hw,
+                                                                   T* __restrict__ out, RescaleArgs a) {
+    const int b = blockIdx.y;
+    const unsigned char* src = x + (long)b * c * hw;
+    T* dst = out + (long)b * c * hw;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long)gridDim.x * blockDim.x)
+        for (int ch = 0; ch < c; ++ch)
+            ElemTraits<T>::store(dst + (long)ch * hw + p, rescale_one<T>((float)src[p * c + ch], a));
+}
+
 // Single-lane vector load/store; every other launch on the stream is ordered after it.
 __global__ void advance_counter_kernel(int* counter, int delta) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -441,6 +454,21 @@ extern "C" int dm_images_to_u8(const void* x, int dtype, int batch, int c, long 
     } else {
         return DM_ERR_ARG;
     }
+    return dm_check_launch();
+}
+
+extern "C" int dm_u8_to_images(const unsigned char* x, int batch, int c, long hw, float old_min, float old_span,
+                               float new_span, float new_min, void* out, int dtype, hipStream_t stream) {
+    if (!x || !out || batch <= 0 || batch > 65535 || c <= 0 || hw <= 0 || old_span == 0.0f) return DM_ERR_ARG;
+    const RescaleArgs a{old_min, old_span, new_span, new_min, 0.f, 0.f, 0};
+    if (dtype == DM_F32)
+        hipLaunchKernelGGL(u8_to_images_kernel<float>, dim3(ew_blocks(hw), batch), dim3(EW_THREADS), 0, stream, x, c, hw,
+                           static_cast<float*>(out), a);
+    else if (dtype == DM_BF16)
+        hipLaunchKernelGGL(u8_to_images_kernel<bf16_t>, dim3(ew_blocks(hw), batch), dim3(EW_THREADS), 0, stream, x, c, hw,
+                           static_cast<bf16_t*>(out), a);
+    else
+        return DM_ERR_ARG;
     return dm_check_launch();
 }
 

@@ -115,3 +115,41 @@ def images_to_uint8(images: torch.Tensor, old_range: Tuple[float, float] = (-1, 
                                      float(old_max - old_min), 255.0, 0.0, 0.0, 255.0, out.data_ptr(), stream_of(x)),
           "images_to_u8")
     return out
+
+
+def prepare_image_tensor(image, width: int, height: int, dtype: torch.dtype = torch.float32,
+                         device="cuda") -> torch.Tensor:
+    """PIL image (or path) -> (C, H, W) tensor in [-1, 1] on the HIP device (scripts/utils.py:167-214).
+
+    Loading and ``Image.resize`` stay on the host as in the reference; the uint8 pixels are uploaded once and the
+    conversion, ``rescale(.., (0, 255), (-1, 1))`` and the channel move run as one kernel."""
+    import numpy as np
+    from PIL import Image
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("prepare_image_tensor: device must be the HIP device ('cuda'); there is no CPU path")
+    if isinstance(image, str):
+        image = Image.open(image)
+    arr = np.array(image.resize((width, height)))
+    if arr.dtype != np.uint8:
+        raise RuntimeError(f"prepare_image_tensor: {arr.dtype} pixels are not supported (8-bit images only)")
+    if arr.ndim == 2:
+        raise ValueError("prepare_image_tensor: the image has no channel axis (convert it to RGB first)")
+    pix = torch.from_numpy(np.ascontiguousarray(arr)).to(device)
+    h, w, c = pix.shape
+    out = torch.empty(c, h, w, dtype=dtype, device=device)
+    check(_lib.lib().dm_u8_to_images(pix.data_ptr(), 1, c, h * w, 0.0, 255.0, 2.0, -1.0, out.data_ptr(),
+                                     _dm_dtype(out, "prepare_image_tensor"), stream_of(pix)), "u8_to_images")
+    return out
+
+
+def save_images(images: torch.Tensor, output_dir: str = "outputs", prefix: str = "sample"):
+    """(B, C, H, W) images in [-1, 1] -> ``{output_dir}/{prefix}_{i:04d}.png`` (scripts/utils.py:217-247); the
+    pixel conversion is ``images_to_uint8``, only the PNG encoding happens on the host."""
+    import os
+    from PIL import Image
+    os.makedirs(output_dir, exist_ok=True)
+    pixels = images_to_uint8(images).cpu().numpy()
+    for i, img in enumerate(pixels):
+        Image.fromarray(img if img.shape[-1] != 1 else img[..., 0]).save(os.path.join(output_dir, f"{prefix}_{i:04d}.png"))
+    print(f"Saved {len(pixels)} images to {output_dir}/")

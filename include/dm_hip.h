@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 4
+#define DM_ABI_VERSION 5
 
 #define DM_F32 0
 #define DM_BF16 1
@@ -206,6 +206,13 @@ int dm_rescale(const void* x, void* y, long n, int dtype, float old_min, float o
  * (rescale(..., clamp=True) -> move_channel(to="last") -> .to(torch.uint8)) in one pass.  hw = H*W. */
 int dm_images_to_u8(const void* x, int dtype, int batch, int c, long hw, float old_min, float old_span,
                     float new_span, float new_min, float lo, float hi, unsigned char* out, hipStream_t stream);
+
+/* (B, H, W, C) uint8 pixels -> (B, C, H, W) fp32 / bf16, rescaled as dm_rescale does (no clamp).  Replaces the
+ * tensor conversion + rescale(image, (0, 255), (-1, 1)) + move_channel(to="first") of prepare_image_tensor
+ * (scripts/utils.py:203-212).  A uint8 value converts exactly; in bf16 mode it is first rounded to bf16, as
+ * torch.tensor(array, dtype=torch.bfloat16) does. */
+int dm_u8_to_images(const unsigned char* x, int batch, int c, long hw, float old_min, float old_span, float new_span,
+                    float new_min, void* out, int dtype, hipStream_t stream);
 
 /* Layout / dtype plumbing around the model boundary (fp32 NCHW outside, [rows][C] inside). */
 int dm_nchw_to_rows(const float* src, int batch, int c, int hw, void* dst, long ld, int cpad, int dtype,

@@ -4,8 +4,8 @@ TEST INFRASTRUCTURE ONLY: imported by tests/, tools/gen_golden.py and nothing el
 reference itself: tools/gen_golden.py runs these functions beside scripts/utils.py on the same inputs and
 stores the reference's outputs in tests/golden/postprocess.npz.
 
-Follows scripts/utils.py:15-53 (rescale), :56-94 (move_channel) and the post-processing chain of
-scripts/inference.py:337-343 (rescale to [0, 255] with clamp, channels last, truncate to uint8).
+Follows scripts/utils.py:15-53 (rescale), :56-94 (move_channel), :199-212 (prepare_image_tensor) and the
+post-processing chain of scripts/inference.py:337-343 (rescale to [0, 255] with clamp, channels last, truncate to uint8).
 """
 from typing import Tuple
 
@@ -36,3 +36,10 @@ def move_channel(t: torch.Tensor, to: str = "first") -> torch.Tensor:
 def images_to_uint8(images: torch.Tensor) -> torch.Tensor:
     """scripts/inference.py:337-343: (B, C, H, W) in [-1, 1] -> (B, H, W, C) uint8."""
     return move_channel(rescale(images, (-1, 1), (0, 255), clamp=True), to="last").to(torch.uint8).contiguous()
+
+
+def prepare_image_tensor(image, width: int, height: int, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """scripts/utils.py:199-212 for a PIL image: resize, to tensor, [0, 255] -> [-1, 1], channels first."""
+    import numpy as np
+    t = torch.tensor(np.array(image.resize((width, height))), dtype=dtype)
+    return move_channel(rescale(t, (0, 255), (-1, 1)), to="first")

@@ -30,6 +30,19 @@ def test_oracle_reproduces_reference_vectors():
     assert np.array_equal(image_ref.images_to_uint8(xb).numpy(), g["u8_bf16_1x3x8x12"])
 
 
+def _picture():
+    from PIL import Image
+    return Image.fromarray((tin("post.pic", (29, 37, 3)).abs() * 120.0).clamp(0, 255).to(torch.uint8).numpy())
+
+
+def test_oracle_prepare_image_tensor():
+    g = load_golden("postprocess")
+    for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        out = image_ref.prepare_image_tensor(_picture(), 24, 16, dt)
+        assert out.shape == (3, 16, 24) and out.dtype == dt
+        assert np.array_equal(out.float().numpy(), g["prepare_" + tag]), tag
+
+
 def test_move_channel_views_and_errors():
     from diffusion_model_amd.pipeline import move_channel
     x = torch.arange(2 * 3 * 4 * 5).reshape(2, 3, 4, 5)
@@ -82,3 +95,27 @@ def test_hip_rescale_bit_exact(dev):
     assert torch.equal(rescale(xb.to(dev), (0, 255), (-1, 1)).cpu(), image_ref.rescale(xb, (0, 255), (-1, 1)))
     with pytest.raises(ValueError):
         rescale(x.to(dev), (1, 1), (0, 255))
+
+
+@pytest.mark.gpu
+def test_hip_prepare_and_save_images(dev, tmp_path):
+    from PIL import Image
+    from diffusion_model_amd.pipeline import images_to_uint8, prepare_image_tensor, save_images
+    g = load_golden("postprocess")
+    for dt, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        out = prepare_image_tensor(_picture(), 24, 16, dtype=dt, device=dev)
+        assert out.shape == (3, 16, 24) and out.dtype == dt and out.is_contiguous()
+        assert np.array_equal(out.float().cpu().numpy(), g["prepare_" + tag]), tag
+    path = str(tmp_path / "pic.png")
+    _picture().save(path)
+    from_path = prepare_image_tensor(path, 24, 16, device=dev)
+    assert np.array_equal(from_path.cpu().numpy(), g["prepare_f32"])
+    with pytest.raises(RuntimeError):
+        prepare_image_tensor(_picture(), 24, 16, device="cpu")
+    # round trip through the PNG writer: the files hold exactly the uint8 pixels of the post-processing chain
+    batch = torch.stack([from_path, -from_path])
+    save_images(batch, str(tmp_path / "out"), prefix="t")
+    want = images_to_uint8(batch).cpu().numpy()
+    for i in range(2):
+        got = np.array(Image.open(str(tmp_path / "out" / f"t_{i:04d}.png")))
+        assert np.array_equal(got, want[i]), i
