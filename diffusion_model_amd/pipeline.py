@@ -29,6 +29,15 @@ def initial_latents(sampler: BaseSampler, shape, generator: Optional[torch.Gener
     return fused_axpbypcz(draw_normal(shape, generator, device), float(sampler.initial_scale))
 
 
+def img2img_latents(sampler: BaseSampler, latents: torch.Tensor, strength: float,
+                    generator: Optional[torch.Generator]) -> torch.Tensor:
+    """Image-to-image start (inference.py:273-276): ``sampler.set_strength(strength)`` shortens the schedule, then
+    ``latents + randn * sampler.initial_scale``.  ``latents`` are the encoded input images."""
+    sampler.set_strength(strength=strength)
+    noise = draw_normal(tuple(latents.shape), generator, latents.device)
+    return fused_axpbypcz(latents, 1.0, noise, float(sampler.initial_scale))
+
+
 def guidance_combine(output: torch.Tensor, cfg_scale: float) -> torch.Tensor:
     """cfg_scale * (cond - uncond) + uncond for ``output = cat([cond, uncond])`` (inference.py:313-315)."""
     cond, uncond = output.chunk(2)

@@ -338,6 +338,21 @@ def test_ksampler_steps_against_reference_goldens(dev):
     assert kl.outputs == [] and kl.step_count == 0
 
 
+def test_img2img_start_matches_reference_expression(dev):
+    """inference.py:271-276: set_strength, then latents + randn * initial_scale (generator order: one draw)."""
+    from diffusion_model_amd import pipeline
+    from diffusion_model_amd.sampling import KEulerSampler
+    lat = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(5))
+    s = KEulerSampler(n_inference_steps=20)
+    got = pipeline.img2img_latents(s, lat.to(dev), 0.6, torch.Generator().manual_seed(6))
+    noise = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(6))
+    sig, _ = sched_ref.k_sigmas(20)
+    start = 20 - int(20 * 0.6)
+    assert s.step_count == start and len(s.timesteps) == 20 - start
+    want = lat + noise * torch.tensor(float(sig[start]), dtype=torch.float32)
+    assert max_rel(got, want) < 1e-6
+
+
 def test_cfg_denoise_loop_matches_oracle(model_f32, dev):
     """inference.py's K-Euler loop with classifier-free guidance, 3 steps at 16x16, against the CPU oracle."""
     from diffusion_model_amd import pipeline
