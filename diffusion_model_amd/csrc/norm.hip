@@ -134,6 +134,16 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
     __shared__ float g_mean[64], g_rstd[64];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int cpg = c / groups;
+    // affine parameters of this thread's channels, requested now so that their latency overlaps the statistics
+    // loads below instead of following the second barrier
+    constexpr int CH_PER_THREAD = GN_MAX_C / GN_THREADS;
+    float gam[CH_PER_THREAD], bet[CH_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < CH_PER_THREAD; ++k) {
+        const int ch = tid + k * GN_THREADS;
+        gam[k] = ch < c ? gamma[ch] : 0.f;
+        bet[k] = ch < c ? beta[ch] : 0.f;
+    }
     // fold the slab partials: 8 threads per group each sum a strided subset in fp64 (fixed order),
     // then the group's first thread adds the 8 sub-sums in order
     __shared__ double sub[64][8][2];
@@ -172,11 +182,15 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
         g_rstd[grp] = (float)(1.0 / sqrt(var + (double)eps));
     }
     __syncthreads();
-    for (int ch = tid; ch < c; ch += GN_THREADS) {
-        const int grp = ch / cpg;
-        const float sc = g_rstd[grp] * gamma[ch];
-        t_scale[ch] = sc;
-        t_shift[ch] = fmaf(-g_mean[grp], sc, beta[ch]);
+#pragma unroll
+    for (int k = 0; k < CH_PER_THREAD; ++k) {
+        const int ch = tid + k * GN_THREADS;
+        if (ch < c) {
+            const int grp = ch / cpg;
+            const float sc = g_rstd[grp] * gam[k];
+            t_scale[ch] = sc;
+            t_shift[ch] = fmaf(-g_mean[grp], sc, bet[k]);
+        }
     }
     __syncthreads();
 
