@@ -420,14 +420,9 @@ template <typename T, int D, int QT, bool DSPLIT = false> int attn_launch_qt(con
     constexpr int VCH0 = DT * 16 / EPC;  // V image: see the kernel
     constexpr int VCH = sizeof(T) == 4 ? (VCH0 | 1) : VCH0 + (6 - VCH0 % 4) % 4;
     constexpr int LDS = 2 * (NKS * KT * 64 + (KT * VCH * 16 + 1023) / 1024 * 1024) + (DSPLIT ? 2 * 4 * (KT / 16) * 64 * 16 : 0);
-    static bool attr_done = false;
+    static DmLdsAttr attr_done;
     auto kfn = attn_kernel<T, D, QT, DSPLIT>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
-            hipSuccess)
-            return DM_ERR_LAUNCH;
-        attr_done = true;
-    }
+    if (const int rc = dm_set_lds_attr(reinterpret_cast<const void*>(kfn), attr_done, LDS)) return rc;
     AttnArgs args = a;
     args.nqblk = DSPLIT ? (a.sq + 15) / 16 : (a.sq + 64 * QT - 1) / (64 * QT);
     const long nblk = (long)args.nqblk * a.heads * batch;
@@ -464,7 +459,7 @@ template <typename T> int attn_dispatch(const AttnArgs& a, int batch, int d, hip
         case 64: return attn_launch<T, 64>(a, batch, s);
         case 80: return attn_launch<T, 80>(a, batch, s);
         case 160: return attn_launch<T, 160>(a, batch, s);
-        default: return DM_ERR_ARG;
+        default: return DM_ERR_HEAD_DIM;
     }
 }
 

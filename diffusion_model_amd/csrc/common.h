@@ -27,6 +27,8 @@ typedef uint16_t bf16_t;  // storage type of a bf16 element
 #define DM_ERR_ARG 1      // invalid argument / unsupported shape
 #define DM_ERR_LAUNCH 2   // HIP reported a launch error
 #define DM_ERR_ALIGN 3    // pointer or leading dimension not 16-byte aligned
+#define DM_ERR_HEAD_DIM 4 // attention head dimension without a kernel instantiation
+#define DM_ERR_TOO_LARGE 5 // problem exceeds the fixed scratch of an allocation-free entry point
 
 // ---- scalar conversions -----------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
@@ -135,5 +137,22 @@ static inline int dm_check_launch() {
     if (e == hipSuccess || e == hipErrorNotReady) return DM_OK;
     fprintf(stderr, "libdm_hip: %s (%s)\n", hipGetErrorName(e), hipGetErrorString(e));
     return DM_ERR_LAUNCH;
+}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device setting: remember, per kernel, on which devices
+// it has been made (one bit per device ordinal; setting it twice is harmless, so no lock is needed).
+struct DmLdsAttr {
+    unsigned long long devices = 0;
+};
+static inline int dm_set_lds_attr(const void* kfn, DmLdsAttr& st, int lds_bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return DM_ERR_LAUNCH;
+    if ((st.devices >> dev) & 1ull) return DM_OK;
+    const hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) {
+        fprintf(stderr, "libdm_hip: hipFuncSetAttribute(%d bytes of LDS): %s\n", lds_bytes, hipGetErrorName(e));
+        return DM_ERR_LAUNCH;
+    }
+    st.devices |= 1ull << dev;
+    return DM_OK;
 }
 static inline bool dm_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -17,9 +17,10 @@ inline int ew_blocks(long n_items) {
 // ---- reverse-process update ------------------------------------------------------------------------
 // Each arithmetic step is a separately rounded fp32 operation (no FMA contraction), in the order
 // the reference's tensor expression evaluates them, so the result is bitwise what fp32 torch gives.
+// `out` may alias `x` (the sampling loop updates the latent in place): neither carries __restrict__.
 template <bool SECOND_IS_EPS>
-__global__ __launch_bounds__(EW_THREADS) void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps,
-                                                                const float* __restrict__ noise, float* __restrict__ out,
+__global__ __launch_bounds__(EW_THREADS) void ddpm_step_kernel(const float* x, const float* __restrict__ eps,
+                                                                const float* __restrict__ noise, float* out,
                                                                 long n, const float* __restrict__ coef,
                                                                 const int* __restrict__ step_index, int clip) {
     long shift = 0;

@@ -953,16 +953,8 @@ struct TileInfo {
     int bm, bn, threads, lds;
 };
 
-template <typename K> int launch_kernel(K kfn, bool& attr_done, const TileInfo& t, const GemmArgs& a, hipStream_t stream) {
-    if (!attr_done) {
-        const hipError_t e =
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, t.lds);
-        if (e != hipSuccess) {
-            fprintf(stderr, "libdm_hip: hipFuncSetAttribute(%d bytes of LDS): %s\n", t.lds, hipGetErrorName(e));
-            return DM_ERR_LAUNCH;
-        }
-        attr_done = true;
-    }
+template <typename K> int launch_kernel(K kfn, DmLdsAttr& attr_done, const TileInfo& t, const GemmArgs& a, hipStream_t stream) {
+    if (const int rc = dm_set_lds_attr(reinterpret_cast<const void*>(kfn), attr_done, t.lds)) return rc;
     const int ntm = (a.M + t.bm - 1) / t.bm, ntn = (a.N + t.bn - 1) / t.bn;
     dim3 grid(a.streamk ? a.streamk : ntm * ntn, a.splitk > 1 ? a.splitk : 1, 1);
     hipLaunchKernelGGL(kfn, grid, dim3(t.threads), t.lds, stream, a);
@@ -970,14 +962,14 @@ template <typename K> int launch_kernel(K kfn, bool& attr_done, const TileInfo& 
 }
 
 template <typename T, int BM, int BN, int WM, int WN> int launch_reg(const GemmArgs& a, hipStream_t s) {
-    static bool done = false;
+    static DmLdsAttr done;
     if (a.streamk) return DM_ERR_ARG;  // the work-list form exists for the direct-to-LDS tiles only
     const TileInfo t{BM, BN, WM * WN * 64, 2 * (BM + BN) * 128};
     return launch_kernel(gemm_reg_kernel<T, BM, BN, WM, WN>, done, t, a, s);
 }
 template <typename T, int BM, int BN, int WM, int WN, int ST, bool EARLY = false>
 int launch_dma(const GemmArgs& a, hipStream_t s) {
-    static bool done = false, done_conv = false;
+    static DmLdsAttr done, done_conv;
     const TileInfo t{BM, BN, WM * WN * 64, ST * (BM + BN) * 128};
     if (a.conv) return launch_kernel(conv3x3_igemm_kernel<T, BM, BN, WM, WN, ST, EARLY>, done_conv, t, a, s);
     return launch_kernel(gemm_dma_kernel<T, BM, BN, WM, WN, ST, EARLY>, done, t, a, s);

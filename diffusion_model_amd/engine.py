@@ -27,17 +27,24 @@ def _rup(x: int, m: int) -> int:
 class Arena:
     """Bump allocator over one device buffer; deterministic addresses so launches can be graph-captured."""
 
-    def __init__(self, device, nbytes: int = 256 << 20):
+    def __init__(self, device, nbytes: int = 256 << 20, on_grow=None):
         self.device = device
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.off = 0
         self.peak = 0
         self.frozen = False  # set while a hipGraph capture is in progress (no regrowth allowed)
         self._old = []       # previous buffers kept alive while views into them may still be in use
+        self._on_grow = on_grow  # called after the buffer was replaced (addresses handed out so far are stale)
 
     def reset(self):
         self.off = 0
-        self._old.clear()
+        if self._old:
+            # kernels on the current stream may still read the retired buffers: tell the caching allocator
+            if self.buf.is_cuda:
+                cur = torch.cuda.current_stream(self.buf.device)
+                for b in self._old:
+                    b.record_stream(cur)
+            self._old.clear()
 
     def mark(self) -> int:
         return self.off
@@ -54,6 +61,8 @@ class Arena:
             self._old.append(self.buf)
             self.buf = torch.empty(max(2 * self.buf.numel(), self.off + nbytes), dtype=torch.uint8, device=self.device)
             # earlier views stay valid in the old buffer; continue in the new one at the same offset
+            if self._on_grow is not None:
+                self._on_grow()
         t = self.buf[self.off:self.off + rows * cols * esz].view(dtype).view(rows, cols)
         self.off += nbytes
         self.peak = max(self.peak, self.off)
@@ -87,6 +96,10 @@ class Engine:
             device = torch.device("cuda", torch.cuda.current_device())
         if dtype not in _DM:
             raise RuntimeError(f"unsupported compute dtype {dtype}; use float32 or bfloat16")
+        if torch.cuda.current_device() != device.index:
+            # kernel launches and per-device kernel attributes go to the CURRENT device: make it the tensors' one
+            # (it stays current afterwards, as after torch.cuda.set_device)
+            torch.cuda.set_device(device)
         key = (str(device), dtype)
         if key not in cls._instances:
             cls._instances[key] = Engine(device, dtype)
@@ -99,7 +112,11 @@ class Engine:
         self.esz = 4 if dtype == torch.float32 else 2
         self.epc = 16 // self.esz
         self.bk = 8 * self.epc
-        self.arena = Arena(device)
+        # Bumped whenever one of the engine-owned buffers (arena, split-K slabs, work-list workspace, statistics)
+        # is replaced by a larger one.  A captured hipGraph bakes those addresses in: whoever holds such a graph
+        # records the generation at capture and re-captures when it has moved.
+        self.generation = 0
+        self.arena = Arena(device, on_grow=self._bump_generation)
         self.ws = torch.empty(64 << 20, dtype=torch.uint8, device=device)  # split-K slabs
         # work-list (stream-K) GEMMs: arrival counters + accumulator slabs; the counters must read zero
         # at every launch (the kernel leaves them zero), so this buffer is never shared with the slabs above
@@ -134,6 +151,14 @@ class Engine:
                     self.tuned[ast.literal_eval(k)] = tuple(v)
 
     # ------------------------------------------------------------------ utilities
+    def _bump_generation(self):
+        self.generation += 1
+
+    def _retire(self, buf: torch.Tensor):
+        """A workspace is being replaced: launches already queued on the current stream may still use it."""
+        buf.record_stream(torch.cuda.current_stream(self.device))
+        self.generation += 1
+
     @property
     def stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -166,6 +191,7 @@ class Engine:
         if self._stats_off + n > self.stats_buf.numel():
             if self.arena.frozen:
                 raise RuntimeError("statistics buffer exhausted during graph capture; run one eager step first")
+            self._retire(self.stats_buf)
             self.stats_buf = torch.zeros(max(2 * self.stats_buf.numel(), n), dtype=torch.float64, device=self.device)
             self._stats_off = self._stats_dirty = 0
         t = self.stats_buf[self._stats_off:self._stats_off + batch * 2 * c].view(batch, 2, c)
@@ -361,7 +387,10 @@ class Engine:
                 sk.value = 1
         else:
             no_legacy = ln_in is not None or ln_out
-            key = (m, pw.n, pw.k, d.conv, d.stride, d.up, d.epi, residual is not None, rowbias is not None, no_legacy)
+            # operands that change what a launch does beside the product (fused statistics, a second k-axis
+            # operand) are part of the key: a tile chosen for one use is never silently applied to another
+            key = (m, pw.n, pw.k, d.conv, d.stride, d.up, d.epi, residual is not None, rowbias is not None, no_legacy,
+                   gn_batch > 0 and self.fuse_gn_stats, bool(d.a2))
             best = self.tuned.get(key)
             if best is None and self.autotune and not self.arena.frozen and self.profile is None:
                 best = self._tune(d, key, legacy=not no_legacy)
@@ -410,6 +439,7 @@ class Engine:
         if need > self.ws.numel():
             if self.arena.frozen:
                 raise RuntimeError("split-K workspace too small during graph capture")
+            self._retire(self.ws)
             self.ws = torch.empty(need * 2, dtype=torch.uint8, device=self.device)
         d.workspace, d.workspace_bytes = self.ws.data_ptr(), self.ws.numel()
 
@@ -420,6 +450,7 @@ class Engine:
         if need > self.ws_sk.numel():
             if self.arena.frozen:
                 raise RuntimeError("stream-K workspace too small during graph capture")
+            self._retire(self.ws_sk)
             self.ws_sk = torch.zeros(need * 2, dtype=torch.uint8, device=self.device)
         d.workspace, d.workspace_bytes = self.ws_sk.data_ptr(), self.ws_sk.numel()
 

@@ -154,8 +154,8 @@ class StepLoop:
         self.T = T
         self.n_noise = n_noise
         self.eng, self.pk = model.hip_pack(device)
-        self.eng.autotune = True  # first (eager) step times tile/split-K candidates per GEMM shape
         self.sig = rt._signature(model)
+        self.generation = -1  # engine buffer generation the captured graph was recorded against
         f32 = dict(dtype=torch.float32, device=device)
         self.x = torch.empty(shape, **f32)
         self.eps = torch.empty(shape, **f32)
@@ -195,13 +195,43 @@ class StepLoop:
               "reverse step")
         check(self.lib.dm_advance_counter(self.counter.data_ptr(), 1, s), "advance_counter")
 
+    def _drop_graph(self):
+        if self.graph:
+            self.lib.dm_graph_destroy(self.graph)
+            self.graph = C.c_void_p()
+
+    def _capture(self):
+        """Record one loop body into ``self.graph``.  Whatever goes wrong, the stream is taken out of capture mode
+        and no half-built graph survives, so the caller can fall back to eager launches and capture again later."""
+        eng = self.eng
+        eng.arena.frozen = True
+        began = False
+        try:
+            check(self.lib.dm_graph_begin(eng.stream), "graph_begin")
+            began = True
+            self._body()
+            began = False
+            check(self.lib.dm_graph_end(eng.stream, C.byref(self.graph)), "graph_end")
+            self.generation = eng.generation
+        except Exception:
+            if began:
+                partial = C.c_void_p()
+                if self.lib.dm_graph_end(eng.stream, C.byref(partial)) == 0 and partial:
+                    self.lib.dm_graph_destroy(partial)
+            self.graph = C.c_void_p()
+            raise
+        finally:
+            eng.arena.frozen = False
+
     def run(self, sched, model, x_T, noises, context, trace):
         if rt._signature(model) != self.sig:  # parameters changed: repack and drop the stale graph
             self.eng, self.pk = model.hip_pack(self.device)
             self.sig = rt._signature(model)
-            if self.graph:
-                self.lib.dm_graph_destroy(self.graph)
-                self.graph = C.c_void_p()
+            self._drop_graph()
+        if self.graph and self.generation != self.eng.generation:
+            # a larger workload on the shared engine replaced the arena or a workspace since the capture: the graph's
+            # kernel arguments (and its memset node) point at retired buffers
+            self._drop_graph()
         caller = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(caller)
         with torch.cuda.stream(self.stream):
@@ -221,18 +251,18 @@ class StepLoop:
                                                 out=self.kvs)
             done = 0
             if not self.graph or not sched.use_hip_graph:
-                self._body()  # eager step: packs/arena are warm afterwards
+                # eager step: packs/arena are warm afterwards.  GEMM shapes without an entry in the tile table are
+                # timed here (and only here: the flag is restored, so plain forwards elsewhere never time candidates)
+                prev_tune, self.eng.autotune = self.eng.autotune, True
+                try:
+                    self._body()
+                finally:
+                    self.eng.autotune = prev_tune
                 done = 1
                 if trace is not None:
                     trace.append(self.x.clone())
                 if sched.use_hip_graph and self.T > 1:
-                    self.eng.arena.frozen = True
-                    try:
-                        check(self.lib.dm_graph_begin(self.eng.stream), "graph_begin")
-                        self._body()
-                        check(self.lib.dm_graph_end(self.eng.stream, C.byref(self.graph)), "graph_end")
-                    finally:
-                        self.eng.arena.frozen = False
+                    self._capture()
             for _ in range(done, self.T):
                 if sched.use_hip_graph:
                     check(self.lib.dm_graph_launch(self.graph, self.eng.stream), "graph_launch")
@@ -242,4 +272,8 @@ class StepLoop:
                     trace.append(self.x.clone())
             result = self.x.clone()
         caller.wait_stream(self.stream)
+        result.record_stream(caller)  # allocated on the loop's stream, consumed on the caller's
+        if trace is not None:
+            for t in trace:
+                t.record_stream(caller)
         return result

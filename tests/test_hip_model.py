@@ -180,6 +180,43 @@ def test_config1_trajectory_f32(model_f32, dev):
     assert max_rel(out, g["traj_latents"][4]) < F32
 
 
+def test_captured_graph_survives_engine_buffer_growth(model_f32, dev):
+    """small -> large -> small on one engine: a larger workload replaces the engine's arena and workspaces between two
+    sampling calls of the same shape; the loop must notice that its captured graph points at retired buffers and
+    capture again (same latents as the first call and as the oracle), not replay into freed memory."""
+    g = load_golden("model")
+    ctx1 = torch.as_tensor(g["context_seed1"]).to(dev)
+    sched = DDPMScheduler(num_train_timesteps=5)
+    x_T = torch.as_tensor(g["traj_xT"]).to(dev)
+    noises = [n.to(dev) for n in torch.as_tensor(g["traj_noises"])]
+    first = sched.sample_from_noise(model_f32, x_T, noises, ctx1)
+    loop = next(iter(sched._loops.values()))
+    assert loop.graph and loop.generation == loop.eng.generation
+    eng = loop.eng
+    gen0, old_ptr = eng.generation, eng.arena.buf.data_ptr()
+    # what a bigger batch / latent would do: outgrow the arena, the work-list workspace and the statistics buffer
+    eng.reset()
+    eng.arena.alloc(eng.arena.buf.numel() // 4 + 64, 4, torch.float32)
+    d = _lib_gemm_desc_dummy()
+    eng._bind_streamk(d, 12, 1 << 16, 4096, 1400)  # 183 MB of slabs > the initial 160 MB
+    assert eng.generation > gen0 and eng.arena.buf.data_ptr() != old_ptr
+    eng.reset()  # retired buffers go back to the allocator ...
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    junk = torch.full((64 << 20,), 7, dtype=torch.float32, device=dev)  # ... and may be handed out again
+    second = sched.sample_from_noise(model_f32, x_T, noises, ctx1)
+    assert loop.generation == eng.generation
+    assert torch.equal(first, second)
+    assert max_rel(second, g["traj_latents"][4]) < F32
+    assert bool((junk == 7).all())  # nothing replayed into memory the engine no longer owns
+    del junk
+
+
+def _lib_gemm_desc_dummy():
+    from diffusion_model_amd._lib import GemmDesc
+    return GemmDesc()
+
+
 def test_eps_bf16_within_stated_tolerance(model_f32, dev):
     g = load_golden("model")
     m = Diffusion()

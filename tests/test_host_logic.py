@@ -189,7 +189,8 @@ def test_deterministic_fill_known_answers():
 
 
 def test_arena_scoping():
-    a = Arena("cpu", nbytes=4096)
+    grown = []
+    a = Arena("cpu", nbytes=4096, on_grow=lambda: grown.append(1))
     x = a.alloc(4, 8, torch.float32)
     m = a.mark()
     y = a.alloc(16, 8, torch.bfloat16)
@@ -199,6 +200,7 @@ def test_arena_scoping():
     assert z.data_ptr() == y.data_ptr()
     big = a.alloc(1024, 1024, torch.float32)  # grows; earlier views stay valid
     assert big.numel() == 1 << 20 and x.shape == (4, 8)
+    assert grown == [1]  # holders of captured graphs learn that the addresses moved
     a.frozen = True
     with pytest.raises(RuntimeError):
         a.alloc(1 << 14, 1 << 12, torch.float32)
