@@ -29,7 +29,9 @@ TILE_DIMS.update({TILE_D256x64_S2: (256, 64), TILE_D128x64_S2: (128, 64), TILE_D
                   TILE_D256x256_S2: (256, 256)})
 ALL_TILES = tuple(TILE_DIMS)
 
-_ERR = {1: "invalid argument / unsupported shape", 2: "HIP launch error", 3: "misaligned pointer or stride"}
+_ERR = {1: "invalid argument / unsupported shape", 2: "HIP launch error", 3: "misaligned pointer or stride",
+        4: "unsupported attention head dimension (kernels exist for 40, 64, 80, 160 and 512)",
+        5: "problem too large for the fixed scratch buffer of this allocation-free entry point"}
 
 
 class GemmDesc(C.Structure):
@@ -69,6 +71,9 @@ _PROTOS = {
     "dm_pack_weight_order": (C.c_int, [_i, _i, _i, _vp]),
     "dm_groupnorm_stats": (C.c_int, [_vp, _l, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "dm_groupnorm_apply": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp]),
+    "dm_groupnorm_default_nsplit": (C.c_int, [_i, _i]),
+    "dm_init": (C.c_int, []),
+    "dm_groupnorm_noalloc": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp]),
     "dm_layernorm": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _f, _vp]),
     "dm_attention": (C.c_int, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dm_embed_tokens": (C.c_int, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp]),
@@ -117,7 +122,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dm_abi_version() != 5:
+        if handle.dm_abi_version() != 6:
             raise RuntimeError("libdm_hip.so ABI version mismatch; rebuild with `python build.py`")
         _lib = handle
     return _lib

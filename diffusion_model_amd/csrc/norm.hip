@@ -354,6 +354,31 @@ int ln_launch(const void* x, long ldx, void* y, long ldy, int rows, int c, const
     return dm_check_launch();
 }
 
+// ---- fixed scratch for the allocation-free GroupNorm entry point -------------------------------------------
+// Slab partials [batch][nsplit][groups][2] of dm_groupnorm_noalloc live in this file-scope device array instead
+// of a caller-provided workspace.  Every device the library runs on holds its own copy (1 MiB) until the process
+// ends.  In host code the array's name is only a stand-in for the symbol: the device address is resolved once per
+// device with hipGetSymbolAddress and kept in g_gn_scratch_ptr; kernels only ever see that pointer.
+constexpr long GN_SCRATCH_FLOATS = 1L << 18;
+static __device__ __align__(256) float scratch[GN_SCRATCH_FLOATS];
+float* g_gn_scratch_ptr[64] = {};
+
+int gn_scratch_for_current_device(float** out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return DM_ERR_LAUNCH;
+    if (!g_gn_scratch_ptr[dev]) {
+        float* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            fprintf(stderr, "libdm_hip: hipGetSymbolAddress(scratch): %s\n", hipGetErrorName(e));
+            return DM_ERR_LAUNCH;
+        }
+        g_gn_scratch_ptr[dev] = ptr;
+    }
+    *out = g_gn_scratch_ptr[dev];
+    return DM_OK;
+}
+
 bool norm_args_ok(const void* x, long ldx, const void* y, long ldy, int c, int dtype) {
     const int epc = dtype == DM_F32 ? 4 : 8;
     return x && (dtype == DM_F32 || dtype == DM_BF16) && c > 0 && c % epc == 0 && ldx % epc == 0 && dm_aligned16(x) &&
@@ -391,6 +416,39 @@ extern "C" int dm_groupnorm_apply_sums(const void* x, long ldx, void* y, long ld
     return dtype == DM_F32
                ? gn_apply_launch<float>(x, ldx, y, ldy, batch, hw, c, groups, nullptr, 0, sums, ld_sums, gamma, beta, eps, silu, stream)
                : gn_apply_launch<bf16_t>(x, ldx, y, ldy, batch, hw, c, groups, nullptr, 0, sums, ld_sums, gamma, beta, eps, silu, stream);
+}
+
+extern "C" int dm_groupnorm_default_nsplit(int batch, int hw) {
+    // slabs of >= 16 rows, about 1024 blocks per launch over the batch, at most 128 slabs per sample
+    if (batch <= 0 || hw <= 0) return 0;
+    int per_sample = 1024 / batch;
+    if (per_sample < 8) per_sample = 8;
+    int n = hw / 16;
+    if (n > per_sample) n = per_sample;
+    if (n > 128) n = 128;
+    return n < 1 ? 1 : n;
+}
+
+extern "C" int dm_init(void) {
+    float* p = nullptr;
+    return gn_scratch_for_current_device(&p);
+}
+
+extern "C" int dm_groupnorm_noalloc(const void* x, long ldx, void* y, long ldy, int batch, int hw, int c, int groups,
+                                    int dtype, const float* gamma, const float* beta, float eps, int silu,
+                                    hipStream_t stream) {
+    if (!norm_args_ok(x, ldx, y, ldy, c, dtype) || !y || !gamma || !beta || batch <= 0 || hw <= 0 || groups <= 0 ||
+        groups > 64 || c % groups)
+        return DM_ERR_ARG;
+    const int nsplit = dm_groupnorm_default_nsplit(batch, hw);
+    if ((long)batch * nsplit * groups * 2 > GN_SCRATCH_FLOATS) return DM_ERR_TOO_LARGE;
+    float* partial = nullptr;
+    if (const int rc = gn_scratch_for_current_device(&partial)) return rc;
+    // every (sample, slab, group) entry the second kernel reads is written by the first: nothing to clear
+    int rc = dm_groupnorm_stats(x, ldx, batch, hw, c, groups, dtype, partial, nsplit, stream);
+    if (rc != DM_OK) return rc;
+    return dm_groupnorm_apply(x, ldx, y, ldy, batch, hw, c, groups, dtype, partial, nsplit, gamma, beta, eps, silu,
+                              stream);
 }
 
 extern "C" int dm_layernorm(const void* x, long ldx, void* y, long ldy, int rows, int c, int dtype, const float* gamma,

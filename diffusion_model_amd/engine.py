@@ -138,7 +138,6 @@ class Engine:
         self._order_cache: Dict[Tuple[int, int, bool], torch.Tensor] = {}
         self.tile_override: Optional[Tuple[int, int]] = None
         self.autotune = os.environ.get("DM_AUTOTUNE", "0") == "1"  # the sampling loop switches it on
-        self.gn_blocks = int(os.environ.get("DM_GN_BLOCKS", "1024"))  # GroupNorm statistics blocks per launch
         self.tuned: Dict[tuple, Tuple[int, int]] = {}
         # DM_TUNE_CACHE=<file>: reuse (and extend) the tuned (tile, split) table across processes, so that a
         # profiled run contains no tuning launches
@@ -566,7 +565,7 @@ class Engine:
                                                        gamma.data_ptr(), beta.data_ptr(), eps, int(silu), self.stream),
                       "groupnorm_apply_sums")
             return out
-        nsplit = max(1, min(hw // 16, max(8, self.gn_blocks // batch), 128))  # slabs of >= 16 rows
+        nsplit = self.lib.dm_groupnorm_default_nsplit(batch, hw)
         part = self.arena.alloc(batch * nsplit, groups * 2, torch.float32)
         with self._prof("groupnorm", float(batch * hw * c * self.esz * 2), f"b={batch} hw={hw} c={c}"):
             check(self.lib.dm_groupnorm_stats(x.data_ptr(), x.stride(0), batch, hw, c, groups, self.dm,

@@ -6,10 +6,15 @@
  * DDPMScheduler.sample (src/schedulers/ddpm_scheduler.py:203) plus the torch.nn operators the
  * model is built from.  Each entry point below therefore cites the reference operator call
  * site(s) it replaces.  All functions:
- *   - take raw device pointers, sizes and a hipStream_t; never allocate, free or synchronise
- *     (so a caller may capture them into a hipGraph); workspaces are passed in by the caller;
- *   - return 0 (DM_OK) or a positive DM_ERR_* code; nothing is printed;
- *   - are re-entrant per stream; there is no global state.
+ *   - take raw device pointers, sizes and a hipStream_t; the compute entry points never allocate device memory,
+ *     free or synchronise (so a caller may capture them into a hipGraph) and take their workspaces from the
+ *     caller; the exceptions are the plumbing calls dm_graph_end / dm_event_create (which create runtime objects)
+ *     and dm_event_elapsed_ms (which waits for the event);
+ *   - return 0 (DM_OK) or a positive DM_ERR_* code (1 argument/shape, 2 HIP launch error, 3 alignment,
+ *     4 attention head dimension without a kernel, 5 too large for a fixed scratch); a HIP runtime error is also
+ *     named on stderr;
+ *   - are re-entrant per stream.  Process-wide state is limited to: a per-kernel, per-device "dynamic LDS limit
+ *     raised" flag; constant 16-byte zero / ones device buffers; the 1 MiB device scratch of dm_groupnorm_noalloc.
  * Activation matrices are row-major [rows][ld] with channels contiguous (row = (batch, y, x)
  * or (batch, token)); `dtype` selects fp32 storage/exact-f32 MFMA or bf16 storage/f32 accumulate.
  */
@@ -22,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 5
+#define DM_ABI_VERSION 6
 
 #define DM_F32 0
 #define DM_BF16 1
@@ -148,6 +153,24 @@ int dm_groupnorm_apply(const void* x, long ldx, void* y, long ldy, int batch, in
 int dm_groupnorm_apply_sums(const void* x, long ldx, void* y, long ldy, int batch, int hw, int c, int groups,
                             int dtype, const double* sums, long ld_sums, const float* gamma, const float* beta,
                             float eps, int silu, hipStream_t stream);
+
+/* Slab count the library itself uses for the two-launch GroupNorm (>= 16 rows per slab, <= 128 slabs). */
+int dm_groupnorm_default_nsplit(int batch, int hw);
+
+/* Resolves, for the CURRENT device, the address of the library's fixed device scratch (see
+ * dm_groupnorm_noalloc).  Optional: the entry point that needs it does the same on its first call on a device;
+ * call dm_init() once per device beforehand when that first call would fall inside a stream capture. */
+int dm_init(void);
+
+/* GroupNorm (+ SiLU) with NO allocation and no workspace argument.  No counterpart in the reference: it exists
+ * for callers that cannot call hipMalloc (code under hipGraph capture, tight serving loops, harnesses that
+ * forbid allocation).  Same result, bit for bit, as dm_groupnorm_stats + dm_groupnorm_apply with
+ * nsplit = dm_groupnorm_default_nsplit(batch, hw); the slab partials live in a 1 MiB file-scope device array that
+ * every device holds for the life of the process.  Returns DM_ERR_TOO_LARGE (5) when
+ * batch * nsplit * groups * 2 floats exceed that array (2^18 floats; e.g. batch <= 512 at 32 groups).
+ * All calls on one device share the array: calls that overlap in time on one device (different streams) race. */
+int dm_groupnorm_noalloc(const void* x, long ldx, void* y, long ldy, int batch, int hw, int c, int groups,
+                         int dtype, const float* gamma, const float* beta, float eps, int silu, hipStream_t stream);
 
 /* LayerNorm over the channel dimension of [rows][c].  Replaces nn.LayerNorm (blocks.py:137,143,149). */
 int dm_layernorm(const void* x, long ldx, void* y, long ldy, int rows, int c, int dtype,

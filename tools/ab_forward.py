@@ -5,7 +5,6 @@
 
 Each arm is a comma-separated list of engine switches applied before (re)tuning:
     streamk=0|1     allow work-list (stream-K) candidates in the GEMM autotuner
-    gn_blocks=N     GroupNorm statistics blocks per launch
 Arms are run interleaved `rounds` times; every visit re-tunes from scratch, so tuning noise shows up
 as spread between visits of the same arm.
 """
@@ -52,8 +51,6 @@ def apply(arm):
             eng._tune_graph = bool(int(v))
         elif k == "legacy":
             Engine._TUNE_LEGACY_SK = bool(int(v))
-        elif k == "gn_blocks":
-            eng.gn_blocks = int(v)
         else:
             setattr(eng, k, int(v))
 

@@ -2,8 +2,7 @@
 """Timing of GroupNorm(+SiLU) and LayerNorm on the U-Net's shapes (HIP events, one process).
 
     python tools/bench_norm.py --dtype bf16 --batch 16
-Environment knobs read by the library / engine: DM_GN_BLOCKS (statistics blocks per launch),
-DM_GN_APPLY_BLOCKS (normalise blocks per launch).
+Environment knob read by the library: DM_GN_APPLY_BLOCKS (normalise blocks per launch).
 """
 import argparse
 import os
