@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from diffusion_model_amd.models import CLIP, Diffusion  # noqa: E402
-from diffusion_model_amd.parallel import gather_latents, init_distributed  # noqa: E402
+from diffusion_model_amd.parallel import gather_latents, init_distributed, shard_bounds  # noqa: E402
 from diffusion_model_amd.schedulers import DDPMScheduler  # noqa: E402
 from diffusion_model_amd.schedulers.base_scheduler import sinusoidal_table  # noqa: E402
 from diffusion_model_amd.weights import deterministic_fill_  # noqa: E402
@@ -31,6 +31,10 @@ from diffusion_model_amd.weights import deterministic_fill_  # noqa: E402
 CONFIGS = {
     2: dict(batch=1, latent=64, dtype="f32", name="config2: SD-1.5 U-Net, 64x64 latent (512^2), batch 1, 50 DDPM steps, fp32"),
     3: dict(batch=16, latent=64, dtype="bf16", name="config3: SD-1.5 U-Net, 64x64 latent (512^2), batch 16, 50 DDPM steps, bf16"),
+    # config 4: ONE job of 128 images; rank r samples images shard_bounds(128, N, r) (64 / 32 / 16 per GPU at
+    # N = 2 / 4 / 8), the latents are all-gathered inside the timed region.  Total work is fixed: strong scaling.
+    4: dict(batch=128, latent=64, dtype="bf16", sharded=True,
+            name="config4: SD-1.5 U-Net, 64x64 latent (512^2), global batch 128 sharded over the GPUs, 50 DDPM steps, bf16"),
 }
 # dense MFMA peaks of MI355X (TFLOP/s): exact-f32 MFMA = vector fp32 rate; bf16 dense (no sparsity)
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
@@ -65,19 +69,35 @@ def cpu_baseline(latent_hw):
     """The CPU oracle (fp32 restatement of the reference) timed on this host's cores, bounded sample."""
     from oracle import unet_ref
     from diffusion_model_amd.weights import fill_state
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    # every core this process may use: the affinity mask, further limited by OMP_NUM_THREADS when the host sets
+    # it (a shared GPU box hands each job a CPU share; os.cpu_count() there is the whole machine)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = min(avail, int(os.environ.get("OMP_NUM_THREADS", "0")) or avail)
     torch.set_num_threads(threads)
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     state = fill_state(unet_ref.diffusion_shapes(), seed=0)
     x = torch.randn(1, 4, latent_hw, latent_hw, generator=torch.Generator().manual_seed(3))
     ctx = torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(1))
     temb = sinusoidal_table(torch.tensor([25]), 320)
     unet_ref.diffusion(state, x, ctx, temb)  # warm-up
-    n = 2
+    n = 3
     t0 = time.perf_counter()
     for _ in range(n):
         unet_ref.diffusion(state, x, ctx, temb)
     fwd = (time.perf_counter() - t0) / n
     return {"value": 1.0 / (50 * fwd), "unit": "images/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count(),
             "sample": f"{n} timed Diffusion forwards of the CPU oracle at batch 1, {latent_hw}x{latent_hw} latent, fp32 "
                       f"(+1 warm-up): {fwd:.3f} s/forward; images/s extrapolated as 1/(50 x forward)"}
 
@@ -85,7 +105,7 @@ def cpu_baseline(latent_hw):
 def pmc_traffic(config, batch, latent):
     """HBM bytes per conv3x3 launch from the committed PMC passes of this workload (tools/pmc_traffic.py);
     None when the run is not one of the profiled configurations."""
-    name = {2: "r01_pmc_traffic_config2_f32.json", 3: "r01_pmc_traffic_config3_bf16.json"}.get(config)
+    name = {2: "r02_pmc_traffic_config2_f32.json", 3: "r02_pmc_traffic_config3_bf16.json"}.get(config)
     if name is None or batch != CONFIGS[config]["batch"] or latent != CONFIGS[config]["latent"]:
         return None
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
@@ -111,6 +131,10 @@ def main():
     if args.batch:
         cfg["batch"] = args.batch
     rank, world, local = init_distributed()
+    global_batch = cfg["batch"] if cfg.get("sharded") else cfg["batch"] * world
+    if cfg.get("sharded"):
+        lo, hi = shard_bounds(cfg["batch"], world, rank)
+        cfg["batch"] = hi - lo
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
@@ -119,14 +143,17 @@ def main():
 
     B, HW, T = cfg["batch"], cfg["latent"], args.ddpm_steps
     model = build_model(device, cfg["dtype"])
-    if args.config == 3:
+    if args.config in (3, 4):
         # config 3 conditions on CLIP output: random-init text encoder of the same dtype, random token ids
         # (seed 2 + rank); the encode runs once per sampling pass, inside the timed region
         with torch.device("meta"):
             clip = CLIP()
         clip = deterministic_fill_(clip.to_empty(device=device), seed=0)
         clip = (clip.bfloat16() if cfg["dtype"] == "bf16" else clip).eval()
-        tokens = torch.randint(0, 49408, (B, 77), generator=torch.Generator().manual_seed(2 + rank)).to(device)
+        if cfg.get("sharded"):  # one global prompt table, every rank takes the rows of its images
+            tokens = torch.randint(0, 49408, (global_batch, 77), generator=torch.Generator().manual_seed(2))[lo:hi].to(device)
+        else:
+            tokens = torch.randint(0, 49408, (B, 77), generator=torch.Generator().manual_seed(2 + rank)).to(device)
         ctx = None
     else:
         clip, tokens = None, None
@@ -178,20 +205,20 @@ def main():
                               round(rate / (1e12 if k in ("conv3x3", "gemm", "attention") else 1e9), 2)}
         result = {
             "metric": "512x512 images/sec, 50-step DDPM, SD-1.5 U-Net",
-            "value": args.steps * B * world / elapsed,
+            "value": args.steps * global_batch / elapsed,
             "unit": "images/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if cfg.get("sharded") else "weak",
             "vs_baseline": None,
             "dtype": cfg["dtype"],
             "data": "synthetic (deterministic random-init weights, "
                     + ("CLIP context from random token ids, " if clip is not None else "seeded random context, ")
                     + "device-generated noise)",
-            "config": {"workload": cfg["name"], "batch_per_gpu": B, "global_batch": B * world,
+            "config": {"workload": cfg["name"], "batch_per_gpu": B, "global_batch": global_batch,
                        "latent": f"{HW}x{HW}", "ddpm_steps": T, "hip_graph": sched.use_hip_graph,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_igemm_kernel",

@@ -804,6 +804,340 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_
 }
 
 // ------------------------------------------------------------------------------------------------
+// 256 x 256 block tile, 8 waves (2 x 4), 128 x 64 outputs per wave, two waves per SIMD taking turns
+// ------------------------------------------------------------------------------------------------
+// Why this tile exists: a 128 x 128 tile pulls (128 + 128) x 128 B through the CU's vector-memory path for
+// every 512 MFMA cycles (64 B per clock, that path's whole width); here it is 512 x 128 B per 2048 cycles, half
+// of that.  The k-tile (128 bytes of k) lives in LDS as four "halves" of 128 rows:
+//   A0 / A1: for both wave rows wm, fragments i = 4*ih .. 4*ih+3 of the wave's 128 output rows
+//            (LDS row = wm*64 + (i & 3)*16 + r  <->  tile row wm*128 + i*16 + r)
+//   W0 / W1: for all four wave columns wn, fragments j = 2*jh, 2*jh+1 of the wave's 64-column group
+//            (LDS row = wn*32 + (j & 1)*16 + r  <->  packed weight row wn*64 + j*16 + r)
+// and a wave walks its output tile in four quadrants (ih, jh) = (0,0) (0,1) (1,1) (1,0): after the first quadrant's
+// fragment reads W0 and A0 are dead, after the second W1, after the third A1, so every half is refilled with the
+// k-tile TWO steps ahead right after its last read - almost two k-tiles of latency cover per request, inside two
+// stages (128 KiB).  All fragments of a k-tile stay in registers (A half 32 + W 32 registers besides the 128
+// accumulators), so the fourth quadrant reads nothing.
+// Schedule: a phase is [R: refill requests, fragment reads, counted vmcnt] barrier [M: 16 MFMAs] barrier.  Wave row 1
+// runs one barrier behind wave row 0, so on every SIMD one wave is in its M slot while the other is in its R slot.
+// Hazards (slot numbers count barriers; wave row 0 reads phase p in slot 2p, wave row 1 in slot 2p+1):
+//   RAW  a half read in phase p+1 is waited for (own DMA pieces, counted vmcnt) at the end of R(p) by every wave,
+//        i.e. before barriers 2p / 2p+1, and first read in slot 2p+2;
+//   WAR  a half last read in phase p is refilled in R(p+1), i.e. after barrier 2p+1, which both wave rows reach
+//        only with those reads returned (lgkmcnt(0) closes every R).
+// Per thread and k-tile the requests are issued in the order W0 A0 W1 A1 (two 16-byte pieces each); the counted waits
+// below follow from that order.
+template <int OFF> __device__ __forceinline__ void lds_read_b128(u32x4& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+
+template <typename T, int IH, int JH>
+__device__ __forceinline__ void wide_quadrant(f32x4 (&acc)[8][4], const u32x4 (&afr)[4][2], const u32x4 (&wfr)[2][2][2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) Mma16<T>::mma(acc[4 * IH + ii][2 * JH + jj], wfr[JH][jj][ks], afr[ii][ks]);
+}
+
+template <typename T, bool CONV>
+__device__ __forceinline__ void gemm_wide_body(const GemmArgs& p) {
+    constexpr int BM = 256, BN = 256, NT = 512, FM = 8;
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int BK = 8 * EPC;
+    constexpr int HALF = 128 * 128;   // bytes: 128 LDS rows of 128 B
+    constexpr int STAGE = 4 * HALF;   // A0 A1 W0 W1
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    const int nkt = p.Kpad / BK;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bool m_fast = (p.conv ? 9 * p.N : p.N) > p.M;
+    const char* zsrc = reinterpret_cast<const char*>(g_zero16);
+    const int lds_wave = wave * 1024;
+    const int lchunk = (tid & 7) ^ ((tid >> 4) & 7);  // logical 16-byte chunk of this thread's DMA slots (see gemm_dma_body)
+    // fragment read addresses inside a stage: one register per k-step and operand, everything else is an immediate
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    uint32_t a_rd[2], w_rd[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int ch = ((ks * 4 + fq) ^ ((fr >> 1) & 7)) << 4;
+        a_rd[ks] = lds0 + (wm * 64 + fr) * 128 + ch;
+        w_rd[ks] = lds0 + 2 * HALF + (wn * 32 + fr) * 128 + ch;
+    }
+    // DMA slots of this thread in every half: LDS rows lr = (tid >> 3) + 64 * it, it = 0, 1
+    const int r16 = (tid >> 3) & 15;
+    const int a_sub = ((tid >> 7) & 3) * 16 + r16;             // + it*128 + h*64: tile row
+    const int w_sub = (tid >> 8) * 64 + ((tid >> 7) & 1) * 16 + r16;  // + it*128 + h*32: packed weight row of the tile
+
+    long u = 0, u_end = 1;
+    int sk_g = 0;
+    if (p.streamk) {
+        sk_g = xcd_remap(blockIdx.x, gridDim.x);
+        const long U = (long)ntm * ntn * nkt;
+        u = sk_g * U / gridDim.x;
+        u_end = (sk_g + 1) * U / gridDim.x;
+    }
+
+    while (u < u_end) {
+        int tile_id, kt0, kt1;
+        if (p.streamk) {
+            tile_id = (int)(u / nkt);
+            kt0 = (int)(u - (long)tile_id * nkt);
+            kt1 = (int)min((long)nkt, kt0 + (u_end - u));
+            u += kt1 - kt0;
+            __syncthreads();
+        } else {
+            tile_id = xcd_remap(blockIdx.x, ntm * ntn);
+            kt0 = 0;
+            kt1 = nkt;
+            u = u_end;
+        }
+        const int tile_m = m_fast ? tile_id % ntm : tile_id / ntn;
+        const int tile_n = m_fast ? tile_id / ntm : tile_id - tile_m * ntn;
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+        const int nt = kt1 - kt0;
+
+        // ---- source addressing.  Persistent per-thread state is two 32-bit offsets and the tap masks; everything
+        // else about a request (tile origin, k-tile, tap, wave-row / half) is wave-uniform and lives in SGPRs.
+        // A row r = (h, it) of this thread is tile row it*128 + h*64 + a_sub.  In a stride-1, same-size convolution the
+        // input pixel of (output row m, tap) is simply row m + dy*Win + dx of the image matrix, so dense and conv share
+        // "row-linear" addressing; what differs per row is only whether a tap falls outside the image.
+        const uint32_t a_voff = (uint32_t)(((long)a_sub * p.lda + lchunk * EPC) * sizeof(T));
+        const uint32_t a2_voff = (uint32_t)(((long)a_sub * p.lda2 + lchunk * EPC) * sizeof(T));
+        const uint32_t w_voff = (uint32_t)(((long)(tid >> 8) * nkt * 64 + (((tid >> 7) & 1) * 16 + r16)) * 128 + lchunk * 16);
+        // amask[h]: bits 0..9 for it = 0, bits 16..25 for it = 1; bit t = tap t of that row reads real data
+        // (dense: bit 0 = row inside M; conv: taps 0..8 inside the image, bit 9 = the appended pointwise operand)
+        uint32_t amask[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            amask[h] = 0;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int m = m0 + it * 128 + h * 64 + a_sub;
+                uint32_t bits = 0;
+                if (m < p.M) {
+                    if (CONV) {
+                        const int hw = p.Hout * p.Wout;
+                        const int pix = m % hw;
+                        const int y = pix / p.Wout, x = pix - y * p.Wout;
+#pragma unroll
+                        for (int t9 = 0; t9 < 9; ++t9) {
+                            const int iy = y + t9 / 3 - 1, ix = x + t9 % 3 - 1;
+                            if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) bits |= 1u << t9;
+                        }
+                        if (p.A2) bits |= 1u << 9;
+                    } else {
+                        bits = 1u;
+                    }
+                }
+                amask[h] |= bits << (16 * it);
+            }
+        }
+        int tap[2], c0[2];  // conv: tap and channel offset of the next k-tile to request, per A half
+        if (CONV) {
+            const int kc = kt0 * BK;
+            tap[0] = tap[1] = min(kc / p.Cin, 9);
+            c0[0] = c0[1] = kc - tap[0] * p.Cin;
+        } else {
+            tap[0] = tap[1] = c0[0] = c0[1] = 0;
+        }
+        const int kt_second = (!CONV && p.A2) ? (p.K - p.Cin2) / BK : 0x7fffffff;
+        const long w_tile_base = (long)(n0 >> 6) * nkt * W_KTILE_STEP;
+        // requests of one half of data k-tile `kt` into stage `st` (both wave-uniform)
+        auto issue_a = [&](auto h_, int kt, int st) {
+            constexpr int h = decltype(h_)::value;
+            char* dst = smem + st * STAGE + h * HALF + lds_wave;
+            // wave-uniform part of the source address
+            const char* base;
+            uint32_t voff = a_voff;
+            int bit = 0;
+            if (CONV) {
+                bit = tap[h];
+                if (tap[h] >= 9) {
+                    base = p.A2 + ((long)(m0 + h * 64) * p.lda2 + c0[h]) * sizeof(T);
+                    voff = a2_voff;
+                } else {
+                    const int dy = tap[h] / 3 - 1, dx = tap[h] - (tap[h] / 3) * 3 - 1;
+                    base = p.A + ((long)(m0 + h * 64 + dy * p.Win + dx) * p.lda + c0[h]) * sizeof(T);
+                }
+            } else if (kt >= kt_second) {
+                base = p.A2 + ((long)(m0 + h * 64) * p.lda2 + (long)(kt - kt_second) * BK) * sizeof(T);
+                voff = a2_voff;
+            } else {
+                base = p.A + ((long)(m0 + h * 64) * p.lda + (long)kt * BK) * sizeof(T);
+            }
+            const long row_step = 128L * ((CONV ? tap[h] >= 9 : kt >= kt_second) ? p.lda2 : p.lda) * sizeof(T);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const bool good = (amask[h] >> (16 * it + bit)) & 1u;
+                const char* src = good ? base + it * row_step + voff : zsrc;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + it * 8192), 16, 0, 0);
+            }
+            if (CONV) {
+                c0[h] += BK;
+                if (c0[h] == p.Cin && tap[h] < 9) {
+                    c0[h] = 0;
+                    ++tap[h];
+                }
+            }
+        };
+        auto issue_w = [&](auto h_, int kt, int st) {
+            constexpr int h = decltype(h_)::value;
+            char* dst = smem + st * STAGE + (2 + h) * HALF + lds_wave;
+            const char* base = p.W + w_tile_base + (long)kt * W_KTILE_STEP + h * 4096;
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(base + (long)it * 2 * nkt * W_KTILE_STEP + w_voff),
+                    (__attribute__((address_space(3))) void*)(dst + it * 8192), 16, 0, 0);
+        };
+        constexpr std::integral_constant<int, 0> H0{};
+        constexpr std::integral_constant<int, 1> H1{};
+
+        f32x4 acc[FM][4];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // ---- prologue: k-tiles kt0 and kt0+1 into stages 0 and 1
+        issue_w(H0, kt0, 0); issue_a(H0, kt0, 0); issue_w(H1, kt0, 0); issue_a(H1, kt0, 0);
+        if (nt > 1) { issue_w(H0, kt0 + 1, 1); issue_a(H0, kt0 + 1, 1); issue_w(H1, kt0 + 1, 1); issue_a(H1, kt0 + 1, 1); }
+        if (nt > 1) wait_vm<12>(); else wait_vm<4>();  // W0, A0 of the first k-tile have landed
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();  // wave row 1 runs one barrier behind from here on
+
+        u32x4 afr[4][2], wfr[2][2][2];
+        for (int t = 0; t < nt; ++t) {
+            const int st = t & 1;
+            const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+            const uint32_t a0 = a_rd[0] + st * STAGE, a1 = a_rd[1] + st * STAGE;
+            const uint32_t w0 = w_rd[0] + st * STAGE, w1 = w_rd[1] + st * STAGE;
+            // ---- quadrant (0, 0): reads W0 and A0
+            lds_read_b128<0>(wfr[0][0][0], w0); lds_read_b128<0>(wfr[0][0][1], w1);
+            lds_read_b128<2048>(wfr[0][1][0], w0); lds_read_b128<2048>(wfr[0][1][1], w1);
+            lds_read_b128<0>(afr[0][0], a0); lds_read_b128<0>(afr[0][1], a1);
+            lds_read_b128<2048>(afr[1][0], a0); lds_read_b128<2048>(afr[1][1], a1);
+            lds_read_b128<4096>(afr[2][0], a0); lds_read_b128<4096>(afr[2][1], a1);
+            lds_read_b128<6144>(afr[3][0], a0); lds_read_b128<6144>(afr[3][1], a1);
+            if (more1) wait_vm<10>(); else wait_vm<2>();  // W1 of this k-tile (younger: A1, the whole next k-tile)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            wide_quadrant<T, 0, 0>(acc, afr, wfr);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- quadrant (0, 1): W0 and A0 are free -> k-tile t+2; reads W1
+            if (more2) { issue_w(H0, kt0 + t + 2, st); issue_a(H0, kt0 + t + 2, st); }
+            lds_read_b128<HALF>(wfr[1][0][0], w0); lds_read_b128<HALF>(wfr[1][0][1], w1);
+            lds_read_b128<HALF + 2048>(wfr[1][1][0], w0); lds_read_b128<HALF + 2048>(wfr[1][1][1], w1);
+            if (more2) wait_vm<12>(); else if (more1) wait_vm<8>(); else wait_vm<0>();  // A1 of this k-tile
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            wide_quadrant<T, 0, 1>(acc, afr, wfr);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- quadrant (1, 1): W1 is free; reads A1
+            if (more2) issue_w(H1, kt0 + t + 2, st);
+            lds_read_b128<HALF>(afr[0][0], a0); lds_read_b128<HALF>(afr[0][1], a1);
+            lds_read_b128<HALF + 2048>(afr[1][0], a0); lds_read_b128<HALF + 2048>(afr[1][1], a1);
+            lds_read_b128<HALF + 4096>(afr[2][0], a0); lds_read_b128<HALF + 4096>(afr[2][1], a1);
+            lds_read_b128<HALF + 6144>(afr[3][0], a0); lds_read_b128<HALF + 6144>(afr[3][1], a1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            wide_quadrant<T, 1, 1>(acc, afr, wfr);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- quadrant (1, 0): A1 is free; nothing to read; W0, A0 of the next k-tile must have landed
+            if (more2) issue_a(H1, kt0 + t + 2, st);
+            if (more1) { if (more2) wait_vm<12>(); else wait_vm<4>(); }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            wide_quadrant<T, 1, 0>(acc, afr, wfr);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();  // both wave rows have now passed the same number of barriers
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        if (p.streamk && !(kt0 == 0 && kt1 == nkt)) {
+            // partial tile: same slab / ticket protocol as gemm_dma_body
+            const long ut0 = (long)tile_id * nkt;
+            const long U = (long)ntm * ntn * nkt;
+            const int G = gridDim.x;
+            const int g_first = (int)(((ut0 + 1) * G + U - 1) / U) - 1;
+            const int g_last = (int)(((ut0 + nkt) * G + U - 1) / U) - 1;
+            constexpr long SLAB = (long)BM * BN;
+            {
+                float* slab = p.slabs + (2L * sk_g + (kt0 == 0 ? 1 : 0)) * SLAB;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)(SLAB * 4), 0x00020000);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs,
+                                                               ((i * 4 + j) * NT + tid) * 16, 0, 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* ticket = reinterpret_cast<int*>(smem);
+            if (tid == 0)
+                *ticket = __hip_atomic_fetch_add(p.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const bool last = *ticket == g_last - g_first;
+            if (!last) continue;
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(p.counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            for (int c = g_first; c <= g_last; ++c) {
+                const float* slab = p.slabs + (2L * c + (c == g_first ? 1 : 0)) * SLAB;
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(slab + ((i * 4 + j) * NT + tid) * 4);
+                        acc[i][j] = c == g_first ? v : acc[i][j] + v;
+                    }
+            }
+        }
+        // The wave's 128 rows in four passes of 32, fenced from each other: with 128 accumulator registers live, an
+        // epilogue over more fragment rows at once (its loads hoisted for latency) spills by the hundred.
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float ln_mu[2], ln_rs[2];
+            f32x4 ln_cs[4];
+            const int mrow = m0 + wm * 128 + q * 32;
+            ln_row_stats<2>(p, mrow, n0 + wn * 64, fr, fq, ln_mu, ln_rs, ln_cs);
+            epilogue<T, 2>(p, reinterpret_cast<f32x4(&)[2][4]>(acc[2 * q]), mrow, n0 + wn * 64, fr, fq, 0, ln_mu, ln_rs, ln_cs);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(GemmArgs p) { gemm_wide_body<T, false>(p); }
+template <typename T> __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(GemmArgs p) { gemm_wide_body<T, true>(p); }
+
+// ------------------------------------------------------------------------------------------------
 // register-staged main loop
 // ------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
@@ -975,6 +1309,18 @@ int launch_dma(const GemmArgs& a, hipStream_t s) {
     return launch_kernel(gemm_dma_kernel<T, BM, BN, WM, WN, ST, EARLY>, done, t, a, s);
 }
 
+// 256 x 256 ping-pong tile: bf16 only (exact-fp32 MFMA is 16x slower per operand byte: operand traffic is not its limit)
+template <typename T> int launch_wide(const GemmArgs& a, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        static DmLdsAttr done, done_conv;
+        const TileInfo t{256, 256, 512, 2 * 4 * 128 * 128};
+        if (a.conv) return launch_kernel(conv3x3_wide_kernel<T>, done_conv, t, a, s);
+        return launch_kernel(gemm_wide_kernel<T>, done, t, a, s);
+    } else {
+        return DM_ERR_ARG;
+    }
+}
+
 template <typename T> int launch_typed(const GemmArgs& a, int cfg, hipStream_t s) {
     switch (cfg) {
         case DM_TILE_128x128: return launch_reg<T, 128, 128, 2, 2>(a, s);
@@ -994,7 +1340,7 @@ template <typename T> int launch_typed(const GemmArgs& a, int cfg, hipStream_t s
         case DM_TILE_D256x64_S2: return launch_dma<T, 256, 64, 4, 1, 2>(a, s);
         case DM_TILE_D128x64_S2: return launch_dma<T, 128, 64, 4, 1, 2>(a, s);
         case DM_TILE_D64x64_S2: return launch_dma<T, 64, 64, 4, 1, 2>(a, s);
-        case DM_TILE_D256x256_S2: return launch_dma<T, 256, 256, 2, 4, 2>(a, s);
+        case DM_TILE_D256x256_S2: return launch_wide<T>(a, s);
         case DM_TILE_E128x128: return launch_dma<T, 128, 128, 2, 2, 2, true>(a, s);
         case DM_TILE_E128x64: return launch_dma<T, 128, 64, 4, 1, 2, true>(a, s);
         case DM_TILE_E64x64: return launch_dma<T, 64, 64, 4, 1, 2, true>(a, s);
@@ -1012,7 +1358,7 @@ int tile_wave_rows(int cfg) {
         case DM_TILE_64x128: case DM_TILE_D64x128_S3: case DM_TILE_D64x128_S4: case DM_TILE_D128x64_S4:
         case DM_TILE_D128x64_S2: case DM_TILE_E128x64: case DM_TILE_E64x128:
             return 32;
-        case DM_TILE_D256x256_S2: return 128;
+        case DM_TILE_D256x256_S2: return 32;  // its epilogue handles a wave's 128 rows in four passes of 32
         default: return 64;
     }
 }
@@ -1113,11 +1459,15 @@ extern "C" long dm_gemm_workspace_bytes(int M, int N, int splitk) {
 }
 
 namespace {
+// Arrival counters live in a FIXED area at the head of the work-list workspace, whatever the launch: launches of
+// different shapes share one workspace, and a counter area sized per launch would let one launch's accumulator
+// slabs land where a later, larger launch expects counters that read zero.
+constexpr long SK_COUNTER_BYTES = 8L << 20;  // 2M output tiles
 long streamk_counter_bytes(int tile, int M, int N) {
     int bm, bn;
     if (tile_dims(tile, &bm, &bn)) return -1;
     const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-    return (tiles * 4 + 255) / 256 * 256;
+    return tiles * 4 > SK_COUNTER_BYTES ? -1 : SK_COUNTER_BYTES;
 }
 }  // namespace
 
@@ -1130,7 +1480,9 @@ extern "C" int dm_gemm_stats_supported(int tile, int rows_per_batch, int splitk)
 extern "C" long dm_gemm_streamk_workspace_bytes(int tile, int M, int N, int blocks) {
     int bm, bn;
     if (tile_dims(tile, &bm, &bn) || blocks <= 0) return -1;
-    return streamk_counter_bytes(tile, M, N) + 2L * blocks * bm * bn * (long)sizeof(float);
+    const long counters = streamk_counter_bytes(tile, M, N);
+    if (counters < 0) return -1;  // more output tiles than the counter area holds
+    return counters + 2L * blocks * bm * bn * (long)sizeof(float);
 }
 
 extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
@@ -1179,6 +1531,12 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     int bm, bn;
     if (tile_dims(tile, &bm, &bn)) return DM_ERR_ARG;
     if (d->a2 && tile < DM_TILE_D128x128_S2) return DM_ERR_ARG;  // only the direct-to-LDS loop reads a second operand
+    if (tile == DM_TILE_D256x256_S2) {
+        // bf16, whole k-tiles only (conv: channels a multiple of the k-tile; dense: no padded k tail), no legacy split-K
+        // convolutions: stride 1, same size (input pixel = output row + tap offset)
+        if (d->dtype != DM_BF16 || splitk > 1 || (d->conv ? d->cin % bk != 0 : d->kpad != d->k)) return DM_ERR_ARG;
+        if (d->conv && (d->stride != 1 || d->up || d->hin != d->hout || d->win != d->wout)) return DM_ERR_ARG;
+    }
     // folded / produced LayerNorm statistics live in the epilogue: not with the separate split-K reduction
     if ((d->ln_in || d->ln_out) && splitk > 1) return DM_ERR_ARG;
     if (d->ln_in && (!d->ln_colsum || d->conv || !dm_aligned16(d->ln_colsum) || (reinterpret_cast<uintptr_t>(d->ln_in) & 7u)))
@@ -1193,8 +1551,8 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
         const long units = (long)((d->m + bm - 1) / bm) * ((d->n + bn - 1) / bn) * (d->kpad / bk);
         streamk = (long)-splitk < units ? -splitk : (int)units;
         splitk = 1;
-        if (!d->workspace || (reinterpret_cast<uintptr_t>(d->workspace) & 255u) ||
-            d->workspace_bytes < dm_gemm_streamk_workspace_bytes(tile, d->m, d->n, streamk))
+        const long need = dm_gemm_streamk_workspace_bytes(tile, d->m, d->n, streamk);
+        if (!d->workspace || (reinterpret_cast<uintptr_t>(d->workspace) & 255u) || need < 0 || d->workspace_bytes < need)
             return DM_ERR_ARG;
     }
     if (splitk < 1) splitk = 1;

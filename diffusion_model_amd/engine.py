@@ -190,9 +190,12 @@ class Engine:
         if self._stats_off + n > self.stats_buf.numel():
             if self.arena.frozen:
                 raise RuntimeError("statistics buffer exhausted during graph capture; run one eager step first")
+            # Views handed out earlier in this forward keep living in the old buffer; allocation continues at the SAME
+            # offset in the new one (all zeros), so the high-water mark that reset() clears - and that a captured
+            # memset node bakes in - still covers everything a whole forward of this shape touches.
             self._retire(self.stats_buf)
-            self.stats_buf = torch.zeros(max(2 * self.stats_buf.numel(), n), dtype=torch.float64, device=self.device)
-            self._stats_off = self._stats_dirty = 0
+            self.stats_buf = torch.zeros(max(2 * self.stats_buf.numel(), self._stats_off + n), dtype=torch.float64,
+                                         device=self.device)
         t = self.stats_buf[self._stats_off:self._stats_off + batch * 2 * c].view(batch, 2, c)
         self._stats_off += n
         self._stats_dirty = max(self._stats_dirty, self._stats_off)
@@ -445,7 +448,7 @@ class Engine:
     def _bind_streamk(self, d: GemmDesc, tile: int, m: int, n: int, blocks: int):
         need = self.lib.dm_gemm_streamk_workspace_bytes(tile, m, n, blocks)
         if need < 0:
-            raise RuntimeError("stream-K needs a direct-to-LDS tile")
+            raise RuntimeError("the work-list form needs a direct-to-LDS tile and at most 2M output tiles")
         if need > self.ws_sk.numel():
             if self.arena.frozen:
                 raise RuntimeError("stream-K workspace too small during graph capture")
@@ -455,7 +458,7 @@ class Engine:
 
     # Candidate (tile, split-K) pairs are timed once per distinct problem on the real operands (the
     # launch is idempotent: it only rewrites the output) and the winner is cached for the process.
-    _TUNE_TILES = (_lib.TILE_D256x128_S3, _lib.TILE_D128x128_S2, _lib.TILE_D256x64_S2, _lib.TILE_D128x64_S2,
+    _TUNE_TILES = (_lib.TILE_D256x256_S2, _lib.TILE_D256x128_S3, _lib.TILE_D128x128_S2, _lib.TILE_D256x64_S2, _lib.TILE_D128x64_S2,
                    _lib.TILE_D64x128_S3, _lib.TILE_D64x64_S4, _lib.TILE_D64x64_S2, _lib.TILE_D32x64_S4,
                    _lib.TILE_E128x128, _lib.TILE_E128x64)
     _EARLY_REFILL = (_lib.TILE_E128x128, _lib.TILE_E128x64)  # measured to win only on some bf16 shapes
@@ -503,7 +506,9 @@ class Engine:
         best, best_t = None, float("inf")
         for tile in self._TUNE_TILES:
             bm, bn = _lib.TILE_DIMS[tile]
-            if d.npad < _rup(d.n, bn) or (tile == _lib.TILE_D256x128_S3 and d.m < 2048):
+            if d.npad < _rup(d.n, bn) or (tile in (_lib.TILE_D256x128_S3, _lib.TILE_D256x256_S2) and d.m < 2048):
+                continue
+            if tile == _lib.TILE_D256x256_S2 and self.dtype != torch.bfloat16:
                 continue
             if tile in self._EARLY_REFILL and (self.dtype != torch.bfloat16 or not self.tune_early):
                 continue
@@ -529,6 +534,8 @@ class Engine:
                 if grid >= 2 * blocks * nkt:
                     break
                 d.tile, d.splitk = tile, -grid
+                if self.lib.dm_gemm_streamk_workspace_bytes(tile, d.m, d.n, grid) < 0:
+                    break
                 self._bind_streamk(d, tile, d.m, d.n, grid)
                 t = self._time_candidate(d)
                 if t is not None and t < best_t:

@@ -56,7 +56,9 @@ extern "C" {
 #define DM_TILE_D256x64_S2 20
 #define DM_TILE_D128x64_S2 21
 #define DM_TILE_D64x64_S2 22
-#define DM_TILE_D256x256_S2 23 /* 8 waves, each 128x64 */
+#define DM_TILE_D256x256_S2 23 /* bf16 only: 8 waves of 128x64, two per SIMD taking turns between fragment reads and
+                                * MFMAs; half the operand bytes per MFMA of the 128x128 tile.  Whole k-tiles only
+                                * (dense: kpad == k; conv: cin a multiple of 64), convolutions stride 1 / same size */
 /* E: two LDS buffers, a k-tile's fragments are read into registers before its buffer is refilled with the
  * tile two steps ahead (two tiles in flight at the LDS footprint, hence occupancy, of a 2-stage ring) */
 #define DM_TILE_E128x128 24
@@ -135,7 +137,11 @@ typedef struct DmGemmDesc {
 int dm_gemm(const DmGemmDesc* d, hipStream_t stream);
 void dm_gemm_plan(int dtype, int m, int n, int k, int epi, int* tile, int* splitk);
 long dm_gemm_workspace_bytes(int m, int n, int splitk);
-long dm_gemm_streamk_workspace_bytes(int tile, int m, int n, int blocks); /* -1: tile has no work-list form */
+/* -1: the tile has no work-list form, or the problem has more output tiles (2M) than the counter area holds.  The
+ * first 8 MiB of the workspace are the arrival counters (one per output tile; must read zero at launch, left zero),
+ * the accumulator slabs follow; the split is the same for every launch, so launches of any shapes may share one
+ * workspace. */
+long dm_gemm_streamk_workspace_bytes(int tile, int m, int n, int blocks);
 int dm_gemm_stats_supported(int tile, int rows_per_batch, int splitk);
 /* order[p] = source weight row of packed row p (or -1 for a zero row), for p in [0, npad). */
 int dm_pack_weight_order(int n, int npad, int geglu, int* order_host);

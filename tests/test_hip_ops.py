@@ -30,6 +30,12 @@ def rnd(x, dt):
     return x.to(dt).float()
 
 
+def wide_refuses(eng, tile, stride=1, upx=0, cin=64):
+    """The 256x256 ping-pong tile exists for bf16 on whole k-tiles and stride-1 same-size convolutions only; the
+    library refuses it elsewhere (DM_ERR_ARG), which test_wide_tile_is_refused_where_unsupported checks."""
+    return tile == _lib.TILE_D256x256_S2 and (eng.dtype != torch.bfloat16 or stride != 1 or upx or cin % 64)
+
+
 def up(eng, x2d):
     """CPU fp32 [rows, C] -> engine-dtype device rows."""
     return x2d.to(eng.device).to(eng.dtype).contiguous()
@@ -47,6 +53,8 @@ def eng(request, dev):
 @pytest.mark.parametrize("m,n,k", [(64, 320, 320), (77, 640, 768), (200, 1280, 640), (1024, 320, 1280), (130, 4, 64)])
 @pytest.mark.parametrize("tile", (_lib.TILE_AUTO,) + _lib.ALL_TILES)
 def test_gemm_dense(eng, m, n, k, tile):
+    if wide_refuses(eng, tile):
+        pytest.skip("wide tile: bf16 only")
     a = tin("g.a", (m, k)); w = tin("g.w", (n, k), scale=1 / math.sqrt(k)); b = tin("g.b", (n,)); r = tin("g.r", (m, n))
     lin = torch.nn.Linear(k, n)
     with torch.no_grad():
@@ -93,6 +101,8 @@ def test_gemm_streamk(eng, tile, blocks):
     """Work-list form: `blocks` blocks share the (tile, k-tile) list; tiles cut between blocks are summed by
     the last block to arrive.  Two launches in a row: the arrival counters must come back to zero, and the
     result must not depend on arrival order (bitwise equal)."""
+    if wide_refuses(eng, tile):
+        pytest.skip("wide tile: bf16 only")
     m, n, k = 200, 640, 1280
     a = tin("k.a", (m, k)); w = tin("k.w", (n, k), scale=1 / math.sqrt(k)); b = tin("k.b", (n,))
     rb = tin("k.rb", (2, n)); r = tin("k.r", (m, n))
@@ -142,10 +152,13 @@ def test_gemm_streamk_geglu_and_conv(eng, blocks):
 
 
 @pytest.mark.parametrize("tile,sk", [(_lib.TILE_D128x128_S2, 1), (_lib.TILE_D256x128_S3, -100), (_lib.TILE_D64x64_S2, -37),
-                                     (_lib.TILE_D128x64_S2, 1), (_lib.TILE_64x64, 1), (_lib.TILE_D32x64_S4, -9)])
+                                     (_lib.TILE_D128x64_S2, 1), (_lib.TILE_64x64, 1), (_lib.TILE_D32x64_S4, -9),
+                                     (_lib.TILE_D256x256_S2, 1), (_lib.TILE_D256x256_S2, -23)])
 def test_gemm_fused_groupnorm_statistics(eng, tile, sk):
     """The GEMM accumulates per-channel sums of what it stores; GroupNorm then needs no statistics pass.
     Two producers fill the two channel slices of one buffer (the skip-concat case)."""
+    if wide_refuses(eng, tile):
+        pytest.skip("wide tile: bf16 only")
     b, hw, k, n1, n2 = 3, 64, 640, 320, 160
     m = b * hw
     a = tin("fs.a", (m, k)); w1 = tin("fs.w1", (n1, k), scale=1 / math.sqrt(k)); w2 = tin("fs.w2", (n2, k), scale=1 / math.sqrt(k))
@@ -173,10 +186,13 @@ def test_gemm_fused_groupnorm_statistics(eng, tile, sk):
 
 
 @pytest.mark.parametrize("geglu", [False, True])
-@pytest.mark.parametrize("tile,sk", [(_lib.TILE_AUTO, 1), (_lib.TILE_D128x128_S2, -40), (_lib.TILE_D64x64_S2, 1)])
+@pytest.mark.parametrize("tile,sk", [(_lib.TILE_AUTO, 1), (_lib.TILE_D128x128_S2, -40), (_lib.TILE_D64x64_S2, 1),
+                                     (_lib.TILE_D256x256_S2, 1), (_lib.TILE_D256x256_S2, -40)])
 def test_gemm_folded_layernorm(eng, geglu, tile, sk):
     """LayerNorm between two GEMMs never runs as a kernel: the first GEMM accumulates row sums of what it stores,
     the second (weights pre-scaled by gamma, bias + beta W^T) applies mean / rstd in its epilogue."""
+    if wide_refuses(eng, tile):
+        pytest.skip("wide tile: bf16 only")
     m, k0, c = 150, 256, 320
     n = 8 * c if geglu else 3 * c
     a = tin("fl.a", (m, k0)); w0 = tin("fl.w0", (c, k0), scale=1 / math.sqrt(k0)); b0 = tin("fl.b0", (c,)) + 0.7
@@ -219,6 +235,8 @@ def test_gemm_geglu(eng):
 
 @pytest.mark.parametrize("tile,sk", [(_lib.TILE_AUTO, 1)] + [(t, sk) for t in DMA_TILES for sk in (1, -19)])
 def test_gemm_second_operand_and_chain(eng, tile, sk):
+    if wide_refuses(eng, tile):
+        pytest.skip("wide tile: bf16 only")
     """second(first(a) + r) + x as one GEMM over the row [a | r] (linear_geglu_2 -> += residue -> conv_output):
     the k axis is read from two tensors, the seam on a k-tile boundary; work-list splits cross it."""
     m, c = 200, 128
@@ -270,6 +288,8 @@ def test_conv3x3_every_tile(eng, tile, sk):
         conv = torch.nn.Conv2d(cin, cout, 3, stride=stride, padding=1)
         with torch.no_grad():
             conv.weight.copy_(wt); conv.bias.copy_(bias)
+        if wide_refuses(eng, tile, stride, upx, cin) or (tile == _lib.TILE_D256x256_S2 and sk > 1):
+            continue  # (no separate split-K reduction launch for the wide tile either)
         pw = eng.pack_conv3x3(conv)
         rows = eng.nchw_to_rows(x.to(eng.device), cpad=pw.conv_cin)
         xin = F.interpolate(rnd(x, eng.dtype), scale_factor=2, mode="nearest") if upx else rnd(x, eng.dtype)
@@ -286,6 +306,8 @@ def test_conv3x3_with_pointwise_term(eng, tile, sk):
     """conv3x3(a) + conv1x1(x) in one launch (the residual_layer of a ResidualBlock riding in its second conv):
     k runs over the nine taps and then over the second tensor's channels; work-list splits may start or end
     inside either part."""
+    if wide_refuses(eng, tile):
+        pytest.skip("wide tile: bf16 only")
     b, h, w = 2, 8, 6
     for cin, cin2, cout in ((64, 128, 64), (128, 64, 192)):
         a = tin("cp.a", (b, cin, h, w)); x = tin("cp.x", (b, cin2, h, w))
@@ -402,3 +424,63 @@ def test_layout_roundtrip(eng):
     assert float(rows[:, 100:].float().abs().max()) == 0.0
     back = eng.rows_to_nchw(rows, 3, 100, 9, 5)
     assert torch.equal(back.cpu(), rnd(x, eng.dtype))
+
+
+# ------------------------------------------------------------------------------------------- 256x256 ping-pong tile
+WIDE = _lib.TILE_D256x256_S2
+
+
+@pytest.mark.parametrize("sk", [1, -5, -64, -300])
+def test_wide_tile_multi_tile_gemm_and_conv(dev, sk):
+    """Several 256x256 tiles in both directions, ragged edges in M and N, 1 to 45 k-tiles (the prologue, steady
+    state and tail of its counted waits), residual / per-sample bias epilogue, work-list splits mid-tile."""
+    eng = Engine.get(dev, torch.bfloat16)
+    eng.reset()
+    for m, n, k in ((700, 640, 64), (513, 320, 128), (300, 960, 640), (1030, 1280, 1920)):
+        a = tin("w.a", (m, k)); w = tin("w.w", (n, k), scale=1 / math.sqrt(k)); b = tin("w.b", (n,))
+        rb = tin("w.rb", (2, n)); r = tin("w.r", (m, n))
+        lin = torch.nn.Linear(k, n)
+        with torch.no_grad():
+            lin.weight.copy_(w); lin.bias.copy_(b)
+        pw = eng.pack_linear(lin)
+        half = (m + 1) // 2
+        eng.tile_override = (WIDE, sk)
+        out = eng.gemm(up(eng, a), pw, residual=up(eng, r))
+        eng.tile_override = None
+        ref = rnd(a, eng.dtype) @ rnd(w, eng.dtype).t() + b + rnd(r, eng.dtype)
+        assert max_rel(out.float(), ref) < BF16_TOL, (m, n, k)
+    bsz, cin, cout, h, w_ = 3, 320, 640, 16, 16
+    x = tin("wc.x", (bsz, cin, h, w_)); wt = tin("wc.w", (cout, cin, 3, 3), scale=1 / math.sqrt(9 * cin)); bias = tin("wc.b", (cout,))
+    rb = tin("wc.rb", (bsz, cout))
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(wt); conv.bias.copy_(bias)
+    pw = eng.pack_conv3x3(conv)
+    rows = eng.nchw_to_rows(x.to(dev))
+    eng.tile_override = (WIDE, sk)
+    out = eng.gemm(rows, pw, rowbias=rb.to(dev), rows_per_batch=h * w_,
+                   conv=dict(batch=bsz, hin=h, win=w_, hout=h, wout=w_, cin_real=cin))
+    eng.tile_override = None
+    ref = F.conv2d(rnd(x, eng.dtype), rnd(wt, eng.dtype), bias, padding=1) + rb[:, :, None, None]
+    assert max_rel(eng.rows_to_nchw(out, bsz, cout, h, w_), ref) < BF16_TOL
+    assert int(eng.ws_sk[:4096].max()) == 0
+
+
+def test_wide_tile_is_refused_where_unsupported(dev):
+    lin = torch.nn.Linear(320, 320)
+    for dt in (torch.float32, torch.bfloat16):
+        eng = Engine.get(dev, dt)
+        eng.reset()
+        if dt == torch.float32:
+            pw = eng.pack_linear(lin)
+            eng.tile_override = (WIDE, 1)
+            with pytest.raises(RuntimeError):
+                eng.gemm(torch.zeros(64, 320, device=dev), pw)
+        else:
+            conv = torch.nn.Conv2d(64, 64, 3, stride=2, padding=1)
+            pw = eng.pack_conv3x3(conv)
+            eng.tile_override = (WIDE, 1)
+            with pytest.raises(RuntimeError):
+                eng.gemm(torch.zeros(2 * 64, 64, device=dev, dtype=dt), pw,
+                         conv=dict(batch=2, hin=8, win=8, hout=4, wout=4, stride=2, cin_real=64))
+        eng.tile_override = None

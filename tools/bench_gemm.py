@@ -21,6 +21,7 @@ ap.add_argument("--tiles", default="1,11,12,13")
 ap.add_argument("--sk", default="1")
 ap.add_argument("--shapes", default="all")
 ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--custom", default="", help="extra dense shapes m,n,k;m,n,k;... (run instead of the built-in lists)")
 ap.add_argument("--plain", action="store_true", help="pack the wide layers without the GEGLU epilogue")
 ap.add_argument("--ldc0", action="store_true", help="every output row lands on row 0 (store issue cost without the DRAM traffic)")
 ap.add_argument("--apad", type=int, default=0, help="extra elements in the row stride of A (channel-interleave experiments)")
@@ -55,7 +56,7 @@ def time_call(fn, rounds):
     return best[len(best) // 2]
 
 
-def run(kind, cin, cout, hw):
+def run(kind, cin, cout, hw, m_custom=0):
     gen = torch.Generator(device=dev).manual_seed(0)
     if kind == "conv":
         conv = torch.nn.Conv2d(cin, cout, 3, padding=1).to(dev)
@@ -66,7 +67,9 @@ def run(kind, cin, cout, hw):
         flops = 2.0 * m * cout * 9 * cin
         label = f"conv {cin:4d}->{cout:4d} @{hw:2d}^2 m={m}"
     else:
-        if hw == 0:
+        if m_custom:
+            m = m_custom
+        elif hw == 0:
             m = 4096
         else:
             m = B * hw * hw
@@ -95,6 +98,11 @@ def run(kind, cin, cout, hw):
     print(label.ljust(38), " | ".join(res), flush=True)
 
 
+if args.custom:
+    for spec in args.custom.split(";"):
+        m_, n_, k_ = (int(v) for v in spec.split(","))
+        run("gemm", k_, n_, 0, m_custom=m_)
+    sys.exit(0)
 if args.shapes in ("conv", "all"):
     for c in CONV:
         run("conv", *c)
