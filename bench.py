@@ -35,6 +35,10 @@ CONFIGS = {
     # N = 2 / 4 / 8), the latents are all-gathered inside the timed region.  Total work is fixed: strong scaling.
     4: dict(batch=128, latent=64, dtype="bf16", sharded=True,
             name="config4: SD-1.5 U-Net, 64x64 latent (512^2), global batch 128 sharded over the GPUs, 50 DDPM steps, bf16"),
+    # config 5: the whole text-to-image chain at 768x768 (CLIP encode -> 50 DDPM steps at the 96x96 latent -> VAE decode
+    # -> uint8); the value is 768x768 images/s.  fp32 = the reference's precision; --dtype bf16 runs the bf16 kernels.
+    5: dict(batch=1, latent=96, dtype="f32", e2e=True,
+            name="config5: end-to-end txt2img 768x768: CLIP encode + 50 DDPM steps (96x96 latent) + VAE decode + uint8"),
 }
 # dense MFMA peaks of MI355X (TFLOP/s): exact-f32 MFMA = vector fp32 rate; bf16 dense (no sparsity)
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
@@ -122,6 +126,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--dtype", default="", choices=["", "f32", "bf16"], help="override the config's arithmetic type")
     ap.add_argument("--ddpm-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -130,6 +135,9 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.batch:
         cfg["batch"] = args.batch
+    if args.dtype:
+        cfg["dtype"] = args.dtype
+        cfg["name"] += f" [--dtype {args.dtype}]"
     rank, world, local = init_distributed()
     global_batch = cfg["batch"] if cfg.get("sharded") else cfg["batch"] * world
     if cfg.get("sharded"):
@@ -142,8 +150,15 @@ def main():
     torch.cuda.set_device(device)
 
     B, HW, T = cfg["batch"], cfg["latent"], args.ddpm_steps
+    t_setup = time.perf_counter()
     model = build_model(device, cfg["dtype"])
-    if args.config in (3, 4):
+    decoder = None
+    if cfg.get("e2e"):
+        from diffusion_model_amd.models import Decoder
+        from diffusion_model_amd.pipeline import txt2img_ddpm
+        decoder = deterministic_fill_(Decoder().to(device), seed=0)
+        decoder = (decoder.bfloat16() if cfg["dtype"] == "bf16" else decoder).eval()
+    if args.config in (3, 4, 5):
         # config 3 conditions on CLIP output: random-init text encoder of the same dtype, random token ids
         # (seed 2 + rank); the encode runs once per sampling pass, inside the timed region
         with torch.device("meta"):
@@ -164,6 +179,9 @@ def main():
     shape = (B, 4, HW, HW)
 
     def one_step():
+        if decoder is not None:  # tokens -> uint8 pixels, everything on the device
+            pixels, _ = txt2img_ddpm(tokens, clip, model, decoder, sched, 8 * HW, 8 * HW, gen)
+            return pixels
         context = clip(tokens).float() if clip is not None else ctx
         lat = sched.sample(model, shape, context, gen, device)
         return gather_latents(lat) if world > 1 else lat
@@ -174,6 +192,10 @@ def main():
     setup.use_hip_graph = False
     setup.sample(model, shape, clip(tokens).float() if clip is not None else ctx, gen, device)
     del setup
+    if decoder is not None:
+        decoder(torch.zeros(shape, device=device))  # packs the decoder's weights
+    torch.cuda.synchronize(device)
+    setup_s = time.perf_counter() - t_setup
     for _ in range(args.warmup):
         one_step()
     if world > 1:
@@ -190,21 +212,26 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
-    assert torch.isfinite(out).all()
+    assert out.dtype == torch.uint8 or torch.isfinite(out).all()
 
     if rank == 0:
         prof = kernel_class_profile(model, clip(tokens).float() if clip is not None else ctx, HW, B, device)
         conv = prof["conv3x3"]
         tflops = conv["work"] / (conv["ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[cfg["dtype"]]
+        # every kernel class of one U-Net forward against its roofline: MFMA classes (algorithmic 2*M*N*K flops) vs the
+        # dense MFMA peak of the dtype, the others (algorithmic bytes: one read + one write) vs 8 TB/s of HBM
         classes = {}
         for k, v in prof.items():
             rate = v["work"] / (v["ms"] * 1e-3)
+            mfma = k in ("conv3x3", "gemm", "attention")
             classes[k] = {"ms_per_forward": round(v["ms"], 4), "launches": v["launches"],
-                          ("tflops" if k in ("conv3x3", "gemm", "attention") else "gbs"):
-                              round(rate / (1e12 if k in ("conv3x3", "gemm", "attention") else 1e9), 2)}
+                          ("tflops" if mfma else "gbs"): round(rate / (1e12 if mfma else 1e9), 2),
+                          "bound": "mfma" if mfma else "hbm",
+                          "frac": round(rate / (peak * 1e12 if mfma else HBM_PEAK_GBS * 1e9), 4)}
         result = {
-            "metric": "512x512 images/sec, 50-step DDPM, SD-1.5 U-Net",
+            "metric": ("768x768 images/sec, end-to-end txt2img (CLIP + 50-step DDPM + VAE decode)" if cfg.get("e2e")
+                       else "512x512 images/sec, 50-step DDPM, SD-1.5 U-Net"),
             "value": args.steps * global_batch / elapsed,
             "unit": "images/s",
             "n_gpus": world,
@@ -228,6 +255,9 @@ def main():
                          "launches_per_forward": conv["launches"],
                          "avg_launch_us": round(conv["ms"] * 1e3 / conv["launches"], 2)},
             "kernel_classes": classes,
+            "setup_s": round(setup_s, 1),
+            "setup": "model build + deterministic fill, weight packing, first-use tile selection for shapes missing from "
+                     "the committed tile table; outside warm-up and the timed region",
         }
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(HW)

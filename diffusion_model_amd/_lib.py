@@ -55,6 +55,7 @@ class GemmDesc(C.Structure):
         ("stats", C.c_void_p), ("ld_stats", C.c_long),
         ("ln_in", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_out", C.c_void_p),
         ("a2", C.c_void_p), ("lda2", C.c_long), ("cin2", C.c_int),
+        ("pad_hi_only", C.c_int),
     ]
 
 
@@ -69,6 +70,9 @@ _PROTOS = {
     "dm_groupnorm_apply_sums": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _f, _i, _vp]),
     "dm_zero": (C.c_int, [_vp, _l, _vp]),
     "dm_pack_weight_order": (C.c_int, [_i, _i, _i, _vp]),
+    "dm_pack_rows": (C.c_int, [_vp, _l, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "dm_softmax_rows": (C.c_int, [_vp, _l, _i, _i, _f, _i, _vp]),
+    "dm_vae_sample": (C.c_int, [_vp, _vp, _vp, _i, _l, _f, _vp]),
     "dm_groupnorm_stats": (C.c_int, [_vp, _l, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "dm_groupnorm_apply": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp]),
     "dm_groupnorm_default_nsplit": (C.c_int, [_i, _i]),
@@ -122,7 +126,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dm_abi_version() != 6:
+        if handle.dm_abi_version() != 7:
             raise RuntimeError("libdm_hip.so ABI version mismatch; rebuild with `python build.py`")
         _lib = handle
     return _lib

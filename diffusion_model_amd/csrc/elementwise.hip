@@ -285,6 +285,18 @@ __global__ __launch_bounds__(EW_THREADS) void u8_to_images_kernel(const unsigned
             ElemTraits<T>::store(dst + (long)ch * hw + p, rescale_one<T>((float)src[p * c + ch], a));
 }
 
+// VAE encoder tail (src/models/encoder.py:191-212): moments (B, 8, hw) -> (mean + sqrt(exp(clamp(logvar, -30, 20))) * noise) * s
+__global__ __launch_bounds__(EW_THREADS) void vae_sample_kernel(const float* __restrict__ moments, const float* __restrict__ noise,
+                                                                 float* __restrict__ out, int batch, long hw, float scaling) {
+    const long per = 4 * hw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < batch * per; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / per, j = i - b * per;
+        const float mean = moments[b * 2 * per + j];
+        const float lv = fminf(fmaxf(moments[b * 2 * per + per + j], -30.0f), 20.0f);
+        out[i] = __fmul_rn(__fadd_rn(mean, __fmul_rn(sqrtf(expf(lv)), noise[i])), scaling);
+    }
+}
+
 // Single-lane vector load/store; every other launch on the stream is ordered after it.
 __global__ void advance_counter_kernel(int* counter, int delta) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -470,6 +482,14 @@ extern "C" int dm_u8_to_images(const unsigned char* x, int batch, int c, long hw
                            static_cast<bf16_t*>(out), a);
     else
         return DM_ERR_ARG;
+    return dm_check_launch();
+}
+
+extern "C" int dm_vae_sample(const float* moments, const float* noise, float* out, int batch, long hw, float scaling,
+                             hipStream_t stream) {
+    if (!moments || !noise || !out || batch <= 0 || hw <= 0) return DM_ERR_ARG;
+    hipLaunchKernelGGL(vae_sample_kernel, dim3(ew_blocks((long)batch * 4 * hw)), dim3(EW_THREADS), 0, stream, moments, noise,
+                       out, batch, hw, scaling);
     return dm_check_launch();
 }
 

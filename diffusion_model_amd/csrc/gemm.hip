@@ -47,6 +47,7 @@ struct GemmArgs {
     long ldr;
     int M, N, K, Kpad;
     int conv, Hin, Win, Hout, Wout, Cin, stride, up;
+    int padlo;  // zero padding above / left of the image: 1 (padding 1 all round) or 0 (padding only below / right)
     const char* A2;  // second operand appended to the k axis, Cin2 elements per row: conv: a pointwise term (tap 9,
                      // the pixel itself); dense: columns K-Cin2 .. K-1 of A come from this tensor instead
     long lda2;
@@ -119,7 +120,7 @@ __device__ __forceinline__ void init_rows(ARows<A_IT>& r, const GemmArgs& p, int
 // Element offset (and validity) of the 16-byte piece of A for staged row `it`, conv tap `tap`, channel `kc`.
 template <int A_IT>
 __device__ __forceinline__ bool conv_src(const ARows<A_IT>& r, const GemmArgs& p, int it, int tap, int kc, long& e) {
-    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const int dy = tap / 3 - p.padlo, dx = tap - (tap / 3) * 3 - p.padlo;
     int iy, ix;
     bool ok = r.ok[it] && tap < 9;
     if (p.up) {
@@ -1454,6 +1455,55 @@ extern "C" int dm_pack_weight_order(int n, int npad, int geglu, int* order) {
     return DM_OK;
 }
 
+namespace {
+// One thread per 16-byte chunk of the packed image: packed row p, k-chunk kc.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const T* __restrict__ src, long ld, int n, int k, int transposed,
+                                                        T* __restrict__ dst, int npad, int kpad) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int BK = 8 * EPC;
+    const int kchunks = kpad / EPC, nkt = kpad / BK;
+    const long total = (long)npad * kchunks;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(idx / kchunks), kc = (int)(idx - (long)p * kchunks);
+        const int g = p >> 6, j = (p >> 4) & 3, q = (p >> 2) & 3, r = p & 3;
+        const int row = 64 * g + 16 * q + 4 * j + r;  // dm_pack_weight_order, plain form
+        const int k0 = kc * EPC;
+        T v[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int kk = k0 + e;
+            T x = 0;
+            if (row < n && kk < k) x = transposed ? src[(long)kk * ld + row] : src[(long)row * ld + kk];
+            v[e] = x;
+        }
+        const int kt = k0 / BK, kin = k0 - kt * BK;
+        T* out = dst + ((((long)g * nkt + kt) * 64 + (p & 63)) * BK + kin);
+        *reinterpret_cast<u32x4*>(out) = *reinterpret_cast<const u32x4*>(v);
+    }
+}
+}  // namespace
+
+extern "C" int dm_pack_rows(const void* src, long ld, int n, int k, int transposed, void* dst, int npad, int kpad,
+                            int dtype, hipStream_t stream) {
+    if (!src || !dst || n <= 0 || k <= 0 || npad % 64 || npad < n) return DM_ERR_ARG;
+    const int esz = dtype == DM_F32 ? 4 : (dtype == DM_BF16 ? 2 : 0);
+    if (!esz) return DM_ERR_ARG;
+    const int bk = 8 * (16 / esz);
+    if (kpad % bk || kpad < k) return DM_ERR_ARG;
+    if (!dm_aligned16(dst)) return DM_ERR_ALIGN;
+    const long total = (long)npad * (kpad / (16 / esz));
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (dtype == DM_F32)
+        hipLaunchKernelGGL(pack_rows_kernel<float>, dim3((int)blocks), dim3(256), 0, stream, static_cast<const float*>(src),
+                           ld, n, k, transposed, static_cast<float*>(dst), npad, kpad);
+    else
+        hipLaunchKernelGGL(pack_rows_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, stream,
+                           static_cast<const bf16_t*>(src), ld, n, k, transposed, static_cast<bf16_t*>(dst), npad, kpad);
+    return dm_check_launch();
+}
+
 extern "C" long dm_gemm_workspace_bytes(int M, int N, int splitk) {
     return splitk > 1 ? (long)splitk * M * N * (long)sizeof(float) : 0;
 }
@@ -1508,7 +1558,9 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
         }
         if (d->stride != 1 && d->stride != 2) return DM_ERR_ARG;
         if (d->up && (d->stride != 1 || d->hout != 2 * d->hin || d->wout != 2 * d->win)) return DM_ERR_ARG;
-        if (!d->up && (d->hout != (d->hin + 2 - 3) / d->stride + 1 || d->wout != (d->win + 2 - 3) / d->stride + 1))
+        const int pad2 = d->pad_hi_only ? 1 : 2;  // total zero padding per axis
+        if (d->pad_hi_only && (d->up || d->a2)) return DM_ERR_ARG;
+        if (!d->up && (d->hout != (d->hin + pad2 - 3) / d->stride + 1 || d->wout != (d->win + pad2 - 3) / d->stride + 1))
             return DM_ERR_ARG;
         if (d->m % (d->hout * d->wout)) return DM_ERR_ARG;
     } else if (d->k % epc) {
@@ -1535,7 +1587,7 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
         // bf16, whole k-tiles only (conv: channels a multiple of the k-tile; dense: no padded k tail), no legacy split-K
         // convolutions: stride 1, same size (input pixel = output row + tap offset)
         if (d->dtype != DM_BF16 || splitk > 1 || (d->conv ? d->cin % bk != 0 : d->kpad != d->k)) return DM_ERR_ARG;
-        if (d->conv && (d->stride != 1 || d->up || d->hin != d->hout || d->win != d->wout)) return DM_ERR_ARG;
+        if (d->conv && (d->stride != 1 || d->up || d->pad_hi_only || d->hin != d->hout || d->win != d->wout)) return DM_ERR_ARG;
     }
     // folded / produced LayerNorm statistics live in the epilogue: not with the separate split-K reduction
     if ((d->ln_in || d->ln_out) && splitk > 1) return DM_ERR_ARG;
@@ -1577,6 +1629,7 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     a.M = d->m; a.N = d->n; a.K = d->k; a.Kpad = d->kpad;
     a.conv = d->conv; a.Hin = d->hin; a.Win = d->win; a.Hout = d->hout; a.Wout = d->wout;
     a.Cin = d->cin; a.stride = d->stride; a.up = d->up;
+    a.padlo = d->pad_hi_only ? 0 : 1;
     a.A2 = static_cast<const char*>(d->a2); a.lda2 = d->lda2; a.Cin2 = d->cin2;
     a.epi = d->epi;
     a.splitk = splitk;

@@ -307,6 +307,51 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
+// Row softmax in place: x[r][:] = softmax(scale * x[r][:]).  One block per row; three sweeps of the row (maximum, sum of
+// exponentials, normalised values) - the row (tens of KB) stays in L2 between them.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(T* __restrict__ x, long ld, int cols, float scale) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    __shared__ float red[4];
+    T* row = x + (long)blockIdx.x * ld;
+    const int tid = threadIdx.x, nch = cols / EPC;
+    auto block_reduce = [&](float v, bool is_max) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float w = __shfl_xor(v, o);
+            v = is_max ? fmaxf(v, w) : v + w;
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    float m = -INFINITY;
+    for (int c = tid; c < nch; c += 256) {
+        float f[EPC];
+        chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(row + c * EPC), f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) m = fmaxf(m, f[e]);
+    }
+    m = block_reduce(m, true);
+    float sum = 0.f;
+    for (int c = tid; c < nch; c += 256) {
+        float f[EPC];
+        chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(row + c * EPC), f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) sum += expf(scale * (f[e] - m));
+    }
+    sum = block_reduce(sum, false);
+    const float inv = 1.0f / sum;
+    for (int c = tid; c < nch; c += 256) {
+        float f[EPC];
+        chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(row + c * EPC), f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) f[e] = expf(scale * (f[e] - m)) * inv;
+        *reinterpret_cast<u32x4*>(row + c * EPC) = f32_to_chunk<T>(f);
+    }
+}
+
 template <typename T> int gn_stats_launch(const void* x, long ldx, int batch, int hw, int c, int groups, float* partial,
                                           int nsplit, hipStream_t s) {
     const GnGeom g = gn_geom<T>(c);
@@ -449,6 +494,16 @@ extern "C" int dm_groupnorm_noalloc(const void* x, long ldx, void* y, long ldy, 
     if (rc != DM_OK) return rc;
     return dm_groupnorm_apply(x, ldx, y, ldy, batch, hw, c, groups, dtype, partial, nsplit, gamma, beta, eps, silu,
                               stream);
+}
+
+extern "C" int dm_softmax_rows(void* x, long ld, int rows, int cols, float scale, int dtype, hipStream_t stream) {
+    if (!norm_args_ok(x, ld, nullptr, 0, cols, dtype) || rows <= 0 || !(scale > 0.f)) return DM_ERR_ARG;
+    if (dtype == DM_F32)
+        hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3(rows), dim3(256), 0, stream, static_cast<float*>(x), ld, cols, scale);
+    else
+        hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, dim3(rows), dim3(256), 0, stream, static_cast<bf16_t*>(x), ld, cols,
+                           scale);
+    return dm_check_launch();
 }
 
 extern "C" int dm_layernorm(const void* x, long ldx, void* y, long ldy, int rows, int c, int dtype, const float* gamma,

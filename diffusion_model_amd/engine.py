@@ -340,6 +340,7 @@ class Engine:
             m = conv["batch"] * conv["hout"] * conv["wout"]
             d.conv, d.hin, d.win, d.hout, d.wout = 1, conv["hin"], conv["win"], conv["hout"], conv["wout"]
             d.cin, d.stride, d.up = pw.conv_cin, conv.get("stride", 1), conv.get("up", 0)
+            d.pad_hi_only = int(conv.get("pad_hi_only", 0))
             if a.shape[1] != pw.conv_cin:
                 raise RuntimeError("conv input channel mismatch")
             skip = conv.get("skip")
@@ -392,7 +393,7 @@ class Engine:
             # operands that change what a launch does beside the product (fused statistics, a second k-axis
             # operand) are part of the key: a tile chosen for one use is never silently applied to another
             key = (m, pw.n, pw.k, d.conv, d.stride, d.up, d.epi, residual is not None, rowbias is not None, no_legacy,
-                   gn_batch > 0 and self.fuse_gn_stats, bool(d.a2))
+                   gn_batch > 0 and self.fuse_gn_stats, bool(d.a2), d.pad_hi_only)
             best = self.tuned.get(key)
             if best is None and self.autotune and not self.arena.frozen and self.profile is None:
                 best = self._tune(d, key, legacy=not no_legacy)
@@ -581,6 +582,24 @@ class Engine:
                                               groups, self.dm, part.data_ptr(), nsplit, gamma.data_ptr(),
                                               beta.data_ptr(), eps, int(silu), self.stream), "groupnorm_apply")
         return out
+
+    def pack_rows(self, x: torch.Tensor, transposed: bool = False) -> PackedWeight:
+        """An activation matrix as the weight operand of a GEMM: ``x`` [n, k] (or, ``transposed``, [k, n]) re-laid on
+        the device into the packed layout (arena memory: valid for the current forward)."""
+        rows, cols = x.shape
+        n, k = (cols, rows) if transposed else (rows, cols)
+        npad, kpad = _rup(n, 256), _rup(k, self.bk)
+        w = self.new(npad, kpad)
+        check(self.lib.dm_pack_rows(x.data_ptr(), x.stride(0), n, k, int(transposed), w.data_ptr(), npad, kpad, self.dm,
+                                    self.stream), "pack_rows")
+        return PackedWeight(w, n, k, npad, kpad, None)
+
+    def softmax_rows(self, x: torch.Tensor, scale: float) -> torch.Tensor:
+        rows, cols = x.shape
+        with self._prof("softmax", float(rows * cols * self.esz * 2), f"rows={rows} cols={cols}"):
+            check(self.lib.dm_softmax_rows(x.data_ptr(), x.stride(0), rows, cols, float(scale), self.dm, self.stream),
+                  "softmax_rows")
+        return x
 
     def layernorm(self, x: torch.Tensor, gamma, beta, eps: float = 1e-5, out=None) -> torch.Tensor:
         rows, c = x.shape

@@ -5,6 +5,7 @@ from .clip import CLIP, CLIPEmbedding, CLIPLayer
 from .diffusion import Diffusion, FinalLayer
 from .embeddings import TimeEmbedding
 from .unet import SwitchSequential, UNet, Upsample
+from .vae import Decoder, Encoder, VAEAttentionBlock, VAEResidualBlock
 
 __all__ = ["SelfAttention", "CrossAttention", "ResidualBlock", "AttentionBlock", "TimeEmbedding",
-           "Upsample", "SwitchSequential", "UNet", "FinalLayer", "Diffusion", "CLIPEmbedding", "CLIPLayer", "CLIP"]
+           "Upsample", "SwitchSequential", "UNet", "FinalLayer", "Diffusion", "CLIPEmbedding", "CLIPLayer", "CLIP", "Decoder", "Encoder", "VAEResidualBlock", "VAEAttentionBlock"]

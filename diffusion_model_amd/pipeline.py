@@ -64,6 +64,26 @@ def denoise(model, sampler: BaseSampler, context: torch.Tensor, latents: torch.T
     return latents
 
 
+@torch.no_grad()
+def txt2img_ddpm(tokens: torch.Tensor, clip, diffusion, decoder, scheduler, height: int, width: int,
+                 generator: Optional[torch.Generator] = None):
+    """Text-to-image, end to end on the device: the chain that ``scripts/inference.py`` scripts (text encoding
+    :207-228, denoising loop :283-318, decoding :325-332, uint8 conversion :337-343) with the DDPM sampling loop of
+    src/schedulers/ddpm_scheduler.py:163-210 as the denoiser.
+
+    tokens (B, 77) int64 -> (uint8 images (B, height, width, 3), final latents (B, 4, height/8, width/8)).
+    ``decoder`` is this build's VAE decoder (the reference ships none: its decode step is a commented-out call).
+    """
+    if height % 64 or width % 64:
+        raise ValueError("height and width must be multiples of 64 (latent divisible by 8)")  # inference.py:138-141 asks 8
+    require_hip(tokens, "txt2img_ddpm")
+    context = clip(tokens).float()
+    shape = (tokens.shape[0], 4, height // 8, width // 8)
+    latents = scheduler.sample(diffusion, shape, context, generator, tokens.device)
+    images = decoder(latents)
+    return images_to_uint8(images.float()), latents
+
+
 # ---- image range / layout helpers (reference: scripts/utils.py:15-94, scripts/inference.py:337-343) ----------
 def _dm_dtype(t: torch.Tensor, what: str) -> int:
     if t.dtype == torch.float32:

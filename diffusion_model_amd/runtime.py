@@ -403,3 +403,151 @@ def run_clip(eng: Engine, pk: NS, tokens: torch.Tensor):
     for lp in pk.layers:
         x = run_clip_layer(eng, lp, x, batch, s)
     return eng.layernorm(x, pk.ln_w, pk.ln_b, pk.ln_eps)
+
+
+# ----------------------------------------------------------------------------------------------
+# VAE decoder / encoder (this build's own design - the reference has no runnable autoencoder; see models/vae.py)
+# ----------------------------------------------------------------------------------------------
+def pack_vae_residual(m, eng: Engine) -> NS:
+    cin, cout = m.conv_1.in_channels, m.conv_1.out_channels
+    fold = (eng.fuse_skip and isinstance(m.residual_layer, torch.nn.Conv2d) and cin % eng.bk == 0 and cout % eng.bk == 0)
+    return NS(kind="vres", cin=cin, cout=cout,
+              gn1_w=_f32(eng, m.groupnorm_1.weight), gn1_b=_f32(eng, m.groupnorm_1.bias), gn1_eps=m.groupnorm_1.eps,
+              conv1=eng.pack_conv3x3(m.conv_1),
+              gn2_w=_f32(eng, m.groupnorm_2.weight), gn2_b=_f32(eng, m.groupnorm_2.bias), gn2_eps=m.groupnorm_2.eps,
+              conv2=eng.pack_conv3x3(m.conv_2, skip=m.residual_layer if fold else None),
+              res=None if (fold or isinstance(m.residual_layer, torch.nn.Identity)) else eng.pack_conv1x1(m.residual_layer),
+              fold_skip=fold)
+
+
+def _pad_rows(t: torch.Tensor, n: int) -> torch.Tensor:
+    out = torch.zeros((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    out[:t.shape[0]] = t
+    return out
+
+
+def pack_vae_layers(layers, eng: Engine) -> List[NS]:
+    """Sequential layers of the autoencoder -> launch descriptions.  A GroupNorm directly followed by SiLU becomes one
+    fused launch; channel counts that are not multiples of 8 (3, 4) are zero-padded to 8 on the k side, output widths
+    that are not multiples of 4 (the 3 image planes) to 4 on the n side."""
+    from .models.unet import Upsample
+    from .models.vae import VAEAttentionBlock, VAEResidualBlock
+    ops: List[NS] = []
+    layers = list(layers)
+    i = 0
+    while i < len(layers):
+        m = layers[i]
+        if isinstance(m, VAEResidualBlock):
+            ops.append(pack_vae_residual(m, eng))
+        elif isinstance(m, VAEAttentionBlock):
+            c = m.groupnorm.num_channels
+            ops.append(NS(kind="vattn", c=c, gn_w=_f32(eng, m.groupnorm.weight), gn_b=_f32(eng, m.groupnorm.bias),
+                          gn_eps=m.groupnorm.eps, in_proj=eng.pack_linear(m.attention.in_proj),
+                          out_proj=eng.pack_linear(m.attention.out_proj)))
+        elif isinstance(m, Upsample):
+            ops.append(pack_conv_layer(m.conv, eng, up=True))
+        elif isinstance(m, torch.nn.Conv2d):
+            cin, cout = m.in_channels, m.out_channels
+            if m.kernel_size == (1, 1):
+                # 1x1 convolution on rows of width rup(cin, 8); its output feeds a layer that expects rup(cout, 8)
+                kp, npd = _rup(cin, 8), _rup(cout, 8)
+                w = torch.zeros(npd, kp, dtype=torch.float32, device=eng.device)
+                w[:cout, :cin] = m.weight.detach().reshape(cout, cin).to(eng.device, torch.float32)
+                b = torch.zeros(npd, dtype=torch.float32, device=eng.device)
+                if m.bias is not None:
+                    b[:cout] = m.bias.detach().to(eng.device, torch.float32)
+                ops.append(NS(kind="conv1", cin=cin, cout=cout, cols=npd, w=eng.pack_matrix(w, b)))
+            elif m.kernel_size == (3, 3):
+                conv = m
+                npd = _rup(cout, 8) if cout > 4 else 4
+                if npd != cout:  # zero output rows keep the padded columns exactly zero (bias included)
+                    conv = torch.nn.Conv2d(cin, npd, 3, stride=m.stride, padding=1).to(m.weight.device, m.weight.dtype)
+                    with torch.no_grad():
+                        conv.weight.copy_(_pad_rows(m.weight.detach(), npd))
+                        conv.bias.copy_(_pad_rows(m.bias.detach(), npd) if m.bias is not None else torch.zeros(npd))
+                asym = m.stride == (2, 2) and m.padding == (0, 0)
+                if not asym and m.padding != (1, 1):
+                    raise RuntimeError("VAE convolutions are 3x3 with padding 1, or stride 2 with the (0,1,0,1) padding")
+                ops.append(NS(kind="conv", cin=cin, cout=cout, cols=npd, stride=m.stride[0], pad_hi_only=int(asym),
+                              w=eng.pack_conv3x3(conv)))
+            else:
+                raise RuntimeError("unsupported convolution in the autoencoder")
+        elif isinstance(m, torch.nn.GroupNorm):
+            silu = i + 1 < len(layers) and isinstance(layers[i + 1], torch.nn.SiLU)
+            ops.append(NS(kind="gn", c=m.num_channels, w=_f32(eng, m.weight), b=_f32(eng, m.bias), eps=m.eps, silu=silu,
+                          groups=m.num_groups))
+            i += int(silu)
+        else:
+            raise RuntimeError(f"unsupported layer in the autoencoder: {type(m).__name__}")
+        i += 1
+    return ops
+
+
+def run_vae_residual(eng: Engine, pk: NS, x, batch: int, h: int, w: int):
+    hw = h * w
+    out = eng.new(batch * hw, pk.cout)
+    mark = eng.arena.mark()
+    geom = dict(batch=batch, hin=h, win=w, hout=h, wout=w)
+    a = eng.groupnorm(x, batch, hw, pk.gn1_w, pk.gn1_b, pk.gn1_eps, silu=True)
+    a = eng.gemm(a, pk.conv1, conv=dict(geom, cin_real=pk.cin), gn_batch=batch)
+    a = eng.groupnorm(a, batch, hw, pk.gn2_w, pk.gn2_b, pk.gn2_eps, silu=True)
+    if pk.fold_skip:
+        eng.gemm(a, pk.conv2, out=out, conv=dict(geom, cin_real=pk.cout, skip=x), gn_batch=batch)
+    else:
+        skip = x if pk.res is None else eng.gemm(x, pk.res)
+        eng.gemm(a, pk.conv2, out=out, residual=skip, conv=dict(geom, cin_real=pk.cout), gn_batch=batch)
+    eng.arena.release(mark)
+    return out
+
+
+def run_vae_attention(eng: Engine, pk: NS, x, batch: int, s: int):
+    """Single head of width C (512): wider than the flash kernel's LDS tiles allow, so the scores are materialised
+    per sample - Q K^T and P V run on the GEMM kernel with K / V^T packed on the device as its weight operand."""
+    c = pk.c
+    out = eng.new(batch * s, c)
+    mark = eng.arena.mark()
+    a = eng.groupnorm(x, batch, s, pk.gn_w, pk.gn_b, pk.gn_eps, silu=False)
+    qkv = eng.gemm(a, pk.in_proj)
+    o = eng.new(batch * s, c)
+    for i in range(batch):
+        m2 = eng.arena.mark()
+        rows = slice(i * s, (i + 1) * s)
+        q, k, v = qkv[rows, 0:c], qkv[rows, c:2 * c], qkv[rows, 2 * c:3 * c]
+        scores = eng.gemm(q, eng.pack_rows(k), bias=False)
+        eng.softmax_rows(scores, 1.0 / (c ** 0.5))
+        eng.gemm(scores, eng.pack_rows(v, transposed=True), out=o[rows], bias=False)
+        eng.arena.release(m2)
+    eng.gemm(o, pk.out_proj, out=out, residual=x, gn_batch=batch)
+    eng.arena.release(mark)
+    return out
+
+
+def run_vae_layers(eng: Engine, ops: List[NS], x, batch: int, h: int, w: int, nchw_out: Optional[torch.Tensor] = None):
+    """x: engine-dtype rows [batch*h*w, C (padded to 8)].  Returns (rows, channels, h, w); with ``nchw_out`` the last
+    convolution writes fp32 (B, C, H, W) planes there instead."""
+    c = x.shape[1]
+    for idx, op in enumerate(ops):
+        last = idx == len(ops) - 1
+        if op.kind == "vres":
+            x, c = run_vae_residual(eng, op, x, batch, h, w), op.cout
+        elif op.kind == "vattn":
+            x = run_vae_attention(eng, op, x, batch, h * w)
+        elif op.kind == "gn":
+            x = eng.groupnorm(x, batch, h * w, op.w, op.b, op.eps, silu=op.silu, groups=op.groups)
+        elif op.kind == "conv1":
+            x, c = eng.gemm(x, op.w, gn_batch=0), op.cout
+        elif op.kind in ("conv", "up"):
+            if op.kind == "up":
+                ho, wo = 2 * h, 2 * w
+                geom = dict(batch=batch, hin=h, win=w, hout=ho, wout=wo, up=1, cin_real=op.cin)
+            else:
+                ho, wo = ((h - 2) // 2 + 1, (w - 2) // 2 + 1) if op.pad_hi_only else ((h - 1) // op.stride + 1, (w - 1) // op.stride + 1)
+                geom = dict(batch=batch, hin=h, win=w, hout=ho, wout=wo, stride=op.stride, cin_real=op.cin,
+                            pad_hi_only=op.pad_hi_only)
+            if last and nchw_out is not None:
+                eng.gemm(x, op.w, nchw_out=nchw_out, rows_per_batch=ho * wo, conv=geom)
+                x = None
+            else:
+                x = eng.gemm(x, op.w, conv=geom, gn_batch=batch)
+            h, w, c = ho, wo, op.cout
+    return x, c, h, w

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 6
+#define DM_ABI_VERSION 7
 
 #define DM_F32 0
 #define DM_BF16 1
@@ -132,6 +132,10 @@ typedef struct DmGemmDesc {
     const void* a2;
     long lda2;
     int cin2;
+    /* conv only: 0 = zero padding 1 on every side (nn.Conv2d(padding=1)); 1 = padding only below and right, none
+     * above / left, i.e. F.pad(x, (0, 1, 0, 1)) followed by a padding-0 convolution - the stride-2 convolutions of
+     * the VAE encoder (src/models/encoder.py:179-185).  Not with `up`, not with `a2`. */
+    int pad_hi_only;
 } DmGemmDesc;
 
 int dm_gemm(const DmGemmDesc* d, hipStream_t stream);
@@ -145,6 +149,13 @@ long dm_gemm_streamk_workspace_bytes(int tile, int m, int n, int blocks);
 int dm_gemm_stats_supported(int tile, int rows_per_batch, int splitk);
 /* order[p] = source weight row of packed row p (or -1 for a zero row), for p in [0, npad). */
 int dm_pack_weight_order(int n, int npad, int geglu, int* order_host);
+/* Device-side packing of an ACTIVATION matrix into the `w` operand layout, so that a product of two activation
+ * matrices runs on dm_gemm: dst (npad x kpad, blocked and row-permuted as DmGemmDesc.w) holds the n x k matrix
+ * X[i][j] = src[i*ld + j] (transposed == 0) or src[j*ld + i] (transposed != 0), zero padded.  Used for the
+ * single-head attention of the VAE (scores = Q K^T with K packed; output = P V with V packed transposed), whose head
+ * width of 512 does not fit the flash kernel's LDS tiles (mirror of src/models/encoder.py:56-60). */
+int dm_pack_rows(const void* src, long ld, int n, int k, int transposed, void* dst, int npad, int kpad, int dtype,
+                 hipStream_t stream);
 
 /* GroupNorm (+ optional SiLU) over NHWC rows.  Replaces nn.GroupNorm(32, C) + F.silu
  * (blocks.py:58-59,68-69,128; diffusion.py:44-45).  Two launches: per-slab (sum, sumsq)
@@ -177,6 +188,10 @@ int dm_init(void);
  * All calls on one device share the array: calls that overlap in time on one device (different streams) race. */
 int dm_groupnorm_noalloc(const void* x, long ldx, void* y, long ldy, int batch, int hw, int c, int groups,
                          int dtype, const float* gamma, const float* beta, float eps, int silu, hipStream_t stream);
+
+/* In place x[r][:] = softmax(scale * x[r][:]) over `cols` columns (a multiple of 16 bytes) of `rows` rows.  The
+ * softmax of the materialised-score attention above (F.softmax(w / sqrt(d)), src/models/attention.py:38-39). */
+int dm_softmax_rows(void* x, long ld, int rows, int cols, float scale, int dtype, hipStream_t stream);
 
 /* LayerNorm over the channel dimension of [rows][c].  Replaces nn.LayerNorm (blocks.py:137,143,149). */
 int dm_layernorm(const void* x, long ldx, void* y, long ldy, int rows, int c, int dtype,
@@ -242,6 +257,11 @@ int dm_images_to_u8(const void* x, int dtype, int batch, int c, long hw, float o
  * torch.tensor(array, dtype=torch.bfloat16) does. */
 int dm_u8_to_images(const unsigned char* x, int batch, int c, long hw, float old_min, float old_span, float new_span,
                     float new_min, void* out, int dtype, hipStream_t stream);
+
+/* VAE encoder tail (src/models/encoder.py:191-212): moments fp32 (B, 8, hw) = [mean | log-variance] ->
+ * out (B, 4, hw) = (mean + sqrt(exp(clamp(logvar, -30, 20))) * noise) * scaling. */
+int dm_vae_sample(const float* moments, const float* noise, float* out, int batch, long hw, float scaling,
+                  hipStream_t stream);
 
 /* Layout / dtype plumbing around the model boundary (fp32 NCHW outside, [rows][C] inside). */
 int dm_nchw_to_rows(const float* src, int batch, int c, int hw, void* dst, long ld, int cpad, int dtype,
