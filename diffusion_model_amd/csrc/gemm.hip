@@ -249,13 +249,35 @@ __device__ __forceinline__ void ln_row_stats(const GemmArgs& p, int mrow0, int n
     }
 }
 
+// The column-only epilogue terms of a lane (its 16 bias values; GEGLU: 8 value biases in b[0..1], their 8 gate biases
+// in b[2..3]).  A caller that runs the epilogue in several passes fetches them once and hands them in.
+__device__ __forceinline__ void load_bias(const GemmArgs& p, int ngroup0, int fq, f32x4 (&b)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.epi == DM_EPI_GEGLU) {
+        const int half = p.N >> 1;
+        const int nb = (ngroup0 >> 1) + fq * 8;
+        if (nb >= half) return;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            b[j] = *reinterpret_cast<const f32x4*>(p.bias + nb + 4 * j);
+            b[2 + j] = *reinterpret_cast<const f32x4*>(p.bias + half + nb + 4 * j);
+        }
+    } else if (p.bias) {
+        const int ncol0 = ngroup0 + fq * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (ncol0 + 4 * j < p.N) b[j] = *reinterpret_cast<const f32x4*>(p.bias + ncol0 + 4 * j);
+    }
+}
+
 // Epilogue: lane holds, for row m = mrow0 + 16*i + fr, columns ncol0 + 4*j + r (16 consecutive).
 // Column-only terms (bias) are fetched once per lane, outside the row loop; bf16 rows are written as
 // 16-byte pieces.
 template <typename T, int FM>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FM][4], int mrow0, int ngroup0, int fr, int fq,
                                          int kslice, const float (&ln_mu)[FM], const float (&ln_rs)[FM],
-                                         const f32x4 (&ln_cs)[4]) {
+                                         const f32x4 (&ln_cs)[4], const f32x4* pre_bias = nullptr) {
     const int ncol0 = ngroup0 + fq * 16;
     if (p.splitk > 1) {
 #pragma unroll
@@ -290,8 +312,8 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FM][4],
         f32x4 bv[2], bg[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            bv[j] = *reinterpret_cast<const f32x4*>(p.bias + nb + 4 * j);
-            bg[j] = *reinterpret_cast<const f32x4*>(p.bias + half + nb + 4 * j);
+            bv[j] = pre_bias ? pre_bias[j] : *reinterpret_cast<const f32x4*>(p.bias + nb + 4 * j);
+            bg[j] = pre_bias ? pre_bias[2 + j] : *reinterpret_cast<const f32x4*>(p.bias + half + nb + 4 * j);
         }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
@@ -322,7 +344,8 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FM][4],
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         b4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias && ncol0 + 4 * j < p.N) b4[j] = *reinterpret_cast<const f32x4*>(p.bias + ncol0 + 4 * j);
+        if (pre_bias) b4[j] = pre_bias[j];
+        else if (p.bias && ncol0 + 4 * j < p.N) b4[j] = *reinterpret_cast<const f32x4*>(p.bias + ncol0 + 4 * j);
     }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -785,7 +808,6 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
         epilogue<T, FM>(p, acc, m0 + wm * 16 * FM, n0 + wn * 64, fr, fq, blockIdx.y, ln_mu, ln_rs, ln_cs);
     }
 }
-
 // Waves per SIMD that the LDS ring lets a CU hold (capped at 4): the register budget the compiler must
 // respect, so that a rarely taken path (the partial-tile sum) can never cost the main loop its occupancy.
 constexpr int dma_min_waves(int bm, int bn, int waves, int stages) {
@@ -816,16 +838,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_
 //            (LDS row = wn*32 + (j & 1)*16 + r  <->  packed weight row wn*64 + j*16 + r)
 // and a wave walks its output tile in four quadrants (ih, jh) = (0,0) (0,1) (1,1) (1,0): after the first quadrant's
 // fragment reads W0 and A0 are dead, after the second W1, after the third A1, so every half is refilled with the
-// k-tile TWO steps ahead right after its last read - almost two k-tiles of latency cover per request, inside two
-// stages (128 KiB).  All fragments of a k-tile stay in registers (A half 32 + W 32 registers besides the 128
+// k-tile TWO steps ahead soon after its last read (W0 in the second phase, A0 in the third, W1 and A1 in the fourth,
+// which has no reads: the request-issue cost is spread evenly over the phases) - more than one k-tile of latency
+// cover per request, inside two stages (128 KiB).  All fragments of a k-tile stay in registers (A half 32 + W 32 registers besides the 128
 // accumulators), so the fourth quadrant reads nothing.
 // Schedule: a phase is [R: refill requests, fragment reads, counted vmcnt] barrier [M: 16 MFMAs] barrier.  Wave row 1
 // runs one barrier behind wave row 0, so on every SIMD one wave is in its M slot while the other is in its R slot.
 // Hazards (slot numbers count barriers; wave row 0 reads phase p in slot 2p, wave row 1 in slot 2p+1):
 //   RAW  a half read in phase p+1 is waited for (own DMA pieces, counted vmcnt) at the end of R(p) by every wave,
 //        i.e. before barriers 2p / 2p+1, and first read in slot 2p+2;
-//   WAR  a half last read in phase p is refilled in R(p+1), i.e. after barrier 2p+1, which both wave rows reach
-//        only with those reads returned (lgkmcnt(0) closes every R).
+//   WAR  a half last read in phase p is refilled in R(p+1) or later, i.e. after barrier 2p+1, which both wave rows
+//        reach only with those reads returned (lgkmcnt(0) closes every R).
 // Per thread and k-tile the requests are issued in the order W0 A0 W1 A1 (two 16-byte pieces each); the counted waits
 // below follow from that order.
 template <int OFF> __device__ __forceinline__ void lds_read_b128(u32x4& dst, uint32_t addr) {
@@ -1037,11 +1060,11 @@ __device__ __forceinline__ void gemm_wide_body(const GemmArgs& p) {
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
-            // ---- quadrant (0, 1): W0 and A0 are free -> k-tile t+2; reads W1
-            if (more2) { issue_w(H0, kt0 + t + 2, st); issue_a(H0, kt0 + t + 2, st); }
+            // ---- quadrant (0, 1): W0 is refilled with k-tile t+2; reads W1
+            if (more2) issue_w(H0, kt0 + t + 2, st);
             lds_read_b128<HALF>(wfr[1][0][0], w0); lds_read_b128<HALF>(wfr[1][0][1], w1);
             lds_read_b128<HALF + 2048>(wfr[1][1][0], w0); lds_read_b128<HALF + 2048>(wfr[1][1][1], w1);
-            if (more2) wait_vm<12>(); else if (more1) wait_vm<8>(); else wait_vm<0>();  // A1 of this k-tile
+            if (more2) wait_vm<10>(); else if (more1) wait_vm<8>(); else wait_vm<0>();  // A1 of this k-tile
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -1050,8 +1073,8 @@ __device__ __forceinline__ void gemm_wide_body(const GemmArgs& p) {
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
-            // ---- quadrant (1, 1): W1 is free; reads A1
-            if (more2) issue_w(H1, kt0 + t + 2, st);
+            // ---- quadrant (1, 1): A0 is refilled; reads A1
+            if (more2) issue_a(H0, kt0 + t + 2, st);
             lds_read_b128<HALF>(afr[0][0], a0); lds_read_b128<HALF>(afr[0][1], a1);
             lds_read_b128<HALF + 2048>(afr[1][0], a0); lds_read_b128<HALF + 2048>(afr[1][1], a1);
             lds_read_b128<HALF + 4096>(afr[2][0], a0); lds_read_b128<HALF + 4096>(afr[2][1], a1);
@@ -1064,8 +1087,8 @@ __device__ __forceinline__ void gemm_wide_body(const GemmArgs& p) {
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
-            // ---- quadrant (1, 0): A1 is free; nothing to read; W0, A0 of the next k-tile must have landed
-            if (more2) issue_a(H1, kt0 + t + 2, st);
+            // ---- quadrant (1, 0): W1 and A1 are refilled; nothing to read; W0, A0 of the next k-tile must have landed
+            if (more2) { issue_w(H1, kt0 + t + 2, st); issue_a(H1, kt0 + t + 2, st); }
             if (more1) { if (more2) wait_vm<12>(); else wait_vm<4>(); }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -1123,13 +1146,16 @@ __device__ __forceinline__ void gemm_wide_body(const GemmArgs& p) {
         }
         // The wave's 128 rows in four passes of 32, fenced from each other: with 128 accumulator registers live, an
         // epilogue over more fragment rows at once (its loads hoisted for latency) spills by the hundred.
+        f32x4 pre_b[4];
+        load_bias(p, n0 + wn * 64, fq, pre_b);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float ln_mu[2], ln_rs[2];
             f32x4 ln_cs[4];
             const int mrow = m0 + wm * 128 + q * 32;
             ln_row_stats<2>(p, mrow, n0 + wn * 64, fr, fq, ln_mu, ln_rs, ln_cs);
-            epilogue<T, 2>(p, reinterpret_cast<f32x4(&)[2][4]>(acc[2 * q]), mrow, n0 + wn * 64, fr, fq, 0, ln_mu, ln_rs, ln_cs);
+            epilogue<T, 2>(p, reinterpret_cast<f32x4(&)[2][4]>(acc[2 * q]), mrow, n0 + wn * 64, fr, fq, 0, ln_mu, ln_rs, ln_cs,
+                           pre_b);
             __builtin_amdgcn_sched_barrier(0);
         }
     }

@@ -22,6 +22,7 @@ ap.add_argument("--sk", default="1")
 ap.add_argument("--shapes", default="all")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--custom", default="", help="extra dense shapes m,n,k;m,n,k;... (run instead of the built-in lists)")
+ap.add_argument("--nobias", action="store_true", help="launch without the bias vector (epilogue without its column loads)")
 ap.add_argument("--plain", action="store_true", help="pack the wide layers without the GEGLU epilogue")
 ap.add_argument("--ldc0", action="store_true", help="every output row lands on row 0 (store issue cost without the DRAM traffic)")
 ap.add_argument("--apad", type=int, default=0, help="extra elements in the row stride of A (channel-interleave experiments)")
@@ -90,7 +91,7 @@ def run(kind, cin, cout, hw, m_custom=0):
                 continue
             eng.tile_override = (t, sk)
             try:
-                ms = time_call(lambda: eng.gemm(a, pw, out=out, conv=geom), args.rounds)
+                ms = time_call(lambda: eng.gemm(a, pw, out=out, conv=geom, bias=not args.nobias), args.rounds)
                 res.append(f"t{t}/sk{sk}: {ms*1e3:7.1f}us {flops/ms/1e9:7.1f}TF")
             except RuntimeError as ex:
                 res.append(f"t{t}/sk{sk}: ERR")
