@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--ddpm-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--sampler", default="ddpm", choices=["ddpm", "k_euler_cfg"],
+                    help="k_euler_cfg: the scripted loop of the reference's inference.py - 50 K-Euler steps with "
+                         "classifier-free guidance (model batch doubled); a side measurement, not the headline metric")
     args = ap.parse_args()
 
     cfg = dict(CONFIGS[args.config])
@@ -178,7 +181,19 @@ def main():
     gen = torch.Generator(device=device).manual_seed(42 + rank)
     shape = (B, 4, HW, HW)
 
+    if args.sampler == "k_euler_cfg":
+        from diffusion_model_amd.pipeline import denoise, initial_latents
+        from diffusion_model_amd.sampling import KEulerSampler
+        cfg["name"] += " [K-Euler, classifier-free guidance 7.5, model batch doubled]"
+        ksampler = KEulerSampler(n_inference_steps=T)
+        ctx_pair = (ctx if ctx is not None else clip(tokens).float())
+        ctx_pair = torch.cat([ctx_pair, torch.zeros_like(ctx_pair)])  # [conditional | unconditional]
+
     def one_step():
+        if args.sampler == "k_euler_cfg":
+            ksampler.reset()
+            lat = initial_latents(ksampler, shape, gen, device)
+            return denoise(model, ksampler, ctx_pair, lat, cfg_scale=7.5, do_cfg=True, use_hip_graph=not args.no_graph)
         if decoder is not None:  # tokens -> uint8 pixels, everything on the device
             pixels, _ = txt2img_ddpm(tokens, clip, model, decoder, sched, 8 * HW, 8 * HW, gen)
             return pixels

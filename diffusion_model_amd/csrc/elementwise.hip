@@ -81,6 +81,43 @@ __global__ __launch_bounds__(EW_THREADS) void axpbypcz_kernel(const float* __res
     }
 }
 
+// ---- K-sampler loop body (scripts/inference.py:296-318 with src/sampling/k_euler*.py), per-step scalars in device
+// tables indexed by a device-side step counter so that one captured graph serves every step.  Operation order and
+// rounding are those of the eager path (dm_axpbypcz launches), hence of the reference's tensor expressions.
+// out[c][i] = scale[s] * x[i] for c < copies: the model input, duplicated for classifier-free guidance
+__global__ __launch_bounds__(EW_THREADS) void ksampler_input_kernel(const float* __restrict__ x, float* __restrict__ out, long n,
+                                                                     int copies, const float* __restrict__ scale,
+                                                                     const int* __restrict__ step_index) {
+    const float sc = scale[*step_index];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = __fmul_rn(sc, x[i]);
+        for (int c = 0; c < copies; ++c) out[(long)c * n + i] = v;
+    }
+}
+// guided = cfg * (cond - uncond) + uncond (eps = [cond | uncond], when do_cfg); out = x + coef[s][0] * guided
+// (+ coef[s][1] * noise[s] when that coefficient is non-zero).  `out` may alias `x`.
+__global__ __launch_bounds__(EW_THREADS) void ksampler_step_kernel(const float* x, const float* __restrict__ eps,
+                                                                    const float* __restrict__ noise, float* out, long n,
+                                                                    const float* __restrict__ coef,
+                                                                    const int* __restrict__ step_index, float cfg_scale,
+                                                                    int do_cfg) {
+    const int s = *step_index;
+    const float b = coef[2 * s], c = coef[2 * s + 1];
+    const bool add_noise = noise != nullptr && c != 0.0f;
+    const float* nz = noise ? noise + (long)s * n : nullptr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float o = eps[i];
+        if (do_cfg) {
+            const float un = eps[n + i];
+            const float diff = __fadd_rn(__fmul_rn(1.0f, o), __fmul_rn(-1.0f, un));
+            o = __fadd_rn(__fmul_rn(cfg_scale, diff), __fmul_rn(1.0f, un));
+        }
+        float v = __fadd_rn(__fmul_rn(1.0f, x[i]), __fmul_rn(b, o));
+        if (add_noise) v = __fadd_rn(v, __fmul_rn(c, nz[i]));
+        out[i] = v;
+    }
+}
+
 // ---- time path: y[b][n] = sum_k f(x[b][k]) w[n][k] + bias[n]; one wave per output column ----------
 constexpr int LR_BATCH = 8;
 __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
@@ -346,6 +383,23 @@ extern "C" int dm_axpbypcz(const float* x, float alpha, const float* y, float be
     if (!x || !out || n <= 0) return DM_ERR_ARG;
     hipLaunchKernelGGL(axpbypcz_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, stream, x, alpha, y, beta, z, gamma, out,
                        n);
+    return dm_check_launch();
+}
+
+extern "C" int dm_ksampler_input(const float* x, float* out, long n, int copies, const float* scale_table,
+                                 const int* step_index, hipStream_t stream) {
+    if (!x || !out || !scale_table || !step_index || n <= 0 || copies < 1) return DM_ERR_ARG;
+    hipLaunchKernelGGL(ksampler_input_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, stream, x, out, n, copies,
+                       scale_table, step_index);
+    return dm_check_launch();
+}
+
+extern "C" int dm_ksampler_step(const float* x, const float* eps, const float* noise, float* out, long n,
+                                const float* coef, const int* step_index, float cfg_scale, int do_cfg,
+                                hipStream_t stream) {
+    if (!x || !eps || !out || !coef || !step_index || n <= 0) return DM_ERR_ARG;
+    hipLaunchKernelGGL(ksampler_step_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, stream, x, eps, noise, out, n, coef,
+                       step_index, cfg_scale, do_cfg);
     return dm_check_launch();
 }
 

@@ -47,8 +47,18 @@ def guidance_combine(output: torch.Tensor, cfg_scale: float) -> torch.Tensor:
 
 @torch.no_grad()
 def denoise(model, sampler: BaseSampler, context: torch.Tensor, latents: torch.Tensor, cfg_scale: float = 7.5,
-            do_cfg: bool = True) -> torch.Tensor:
-    """Run ``sampler`` over its remaining timesteps; returns the final latents."""
+            do_cfg: bool = True, use_hip_graph: bool = True) -> torch.Tensor:
+    """Run ``sampler`` over its remaining timesteps; returns the final latents.
+
+    With this package's ``Diffusion`` and an Euler / Euler-ancestral sampler the loop body is captured once as a hipGraph
+    and replayed (per-step scalars and the pre-drawn ancestral noise live in device tables); results are bitwise those
+    of the step-by-step path below, which remains for other models and for ``KLMSSampler`` (whose update reads a
+    history of model outputs)."""
+    from .models.diffusion import Diffusion
+    from .sampling import KEulerAncestralSampler, KEulerSampler
+    if (use_hip_graph and isinstance(model, Diffusion) and type(sampler) in (KEulerSampler, KEulerAncestralSampler)
+            and len(sampler.timesteps) > 0):
+        return _denoise_graph(model, sampler, context, latents, cfg_scale, do_cfg)
     batch = latents.shape[0]
     for timestep in sampler.timesteps:
         temb = get_time_embedding(int(timestep)).to(latents.device)
@@ -62,6 +72,46 @@ def denoise(model, sampler: BaseSampler, context: torch.Tensor, latents: torch.T
         latents = sampler.step(latents, output)
     assert latents.shape[0] == batch
     return latents
+
+
+def _denoise_graph(model, sampler, context, latents, cfg_scale, do_cfg):
+    import numpy as np
+    from .sampling import KEulerAncestralSampler
+    from .schedulers.ddpm_scheduler import KStepLoop
+    require_hip(latents, "denoise")
+    n = len(sampler.timesteps)
+    first = sampler.step_count
+    ancestral = isinstance(sampler, KEulerAncestralSampler)
+    scales, coefs = [], []
+    for t in range(first, first + n):
+        s_from, s_to = sampler.sigmas[t], sampler.sigmas[t + 1]
+        scales.append(sampler.get_input_scale(t))
+        if ancestral:  # the scalars KEulerAncestralSampler.step forms
+            s_up = s_to * np.sqrt(1 - (s_to ** 2 / s_from ** 2))
+            s_down = np.sqrt(s_to ** 2 - s_up ** 2)
+            coefs.append([s_down - s_from, s_up])
+        else:
+            coefs.append([s_to - s_from, 0.0])
+    shape = tuple(latents.shape)
+    # the model never touches the sampler's generator: one draw per step, in step order, can be made up front
+    noises = [draw_normal(shape, sampler.generator, latents.device) for _ in range(n)] if ancestral else []
+    eng, _ = model.hip_pack(latents.device)
+    key = (id(model), id(eng), shape, str(latents.device), context.shape[1], type(sampler).__name__, first, n,
+           tuple(float(t) for t in sampler.timesteps), float(cfg_scale), bool(do_cfg))
+    cache = sampler.__dict__.setdefault("_dm_loops", {})
+    loop = cache.get(key)
+    if loop is None:
+        cache.clear()
+        loop = KStepLoop(model, shape, latents.device, context.shape[1], [int(t) for t in sampler.timesteps], scales, coefs,
+                         n_noise=len(noises), cfg_scale=cfg_scale, do_cfg=do_cfg)
+        cache[key] = loop
+    out = loop.run(_GraphSwitch, model, latents, noises, context, None)
+    sampler.step_count += n
+    return out.to(latents.dtype)
+
+
+class _GraphSwitch:
+    use_hip_graph = True
 
 
 @torch.no_grad()

@@ -171,6 +171,9 @@ class StepLoop:
         self.tproj_table = None  # [T][sum of ResidualBlock C_out] time projections of every step, loop order
         self.tproj_row = None
         self.graph = C.c_void_p()
+        # what the model reads and writes inside the loop body (subclasses may put a scaled / duplicated copy of the
+        # latent in front of the model and combine its output themselves)
+        self.model_in, self.model_out = self.x, self.eps
 
     def __del__(self):
         try:
@@ -179,20 +182,27 @@ class StepLoop:
         except Exception:
             pass
 
+    def _pre(self, s):
+        """Launches between the time-row gather and the model (none for DDPM / DDIM)."""
+
+    def _update(self, s):
+        check(self.step_fn(self.x.data_ptr(), self.eps.data_ptr(), self.noise.data_ptr() if self.n_noise else None,
+                           self.x.data_ptr(), self.x.numel(), self.coef.data_ptr(), self.counter.data_ptr(), self.clip, s),
+              "reverse step")
+
     def _body(self):
         s = self.eng.stream
-        B = self.shape[0]
+        B = self.model_in.shape[0]
         # every sample of the batch is at the same timestep: one row of the per-step table of time projections
         # (computed once per sampling call) serves the whole batch through a zero row stride
         n = self.tproj_table.shape[1]
         check(self.lib.dm_gather_row(self.tproj_table.data_ptr(), n, self.counter.data_ptr(), self.tproj_row.data_ptr(),
                                      n, 1, n, s), "gather_row")
+        self._pre(s)
         self.eng.reset()
-        rt.diffusion_forward_into(self.eng, self.pk, self.x, None, self.kvs, self.sk, self.eps,
+        rt.diffusion_forward_into(self.eng, self.pk, self.model_in, None, self.kvs, self.sk, self.model_out,
                                   tproj=self.tproj_row.expand(B, n))
-        check(self.step_fn(self.x.data_ptr(), self.eps.data_ptr(), self.noise.data_ptr() if self.n_noise else None,
-                           self.x.data_ptr(), self.x.numel(), self.coef.data_ptr(), self.counter.data_ptr(), self.clip, s),
-              "reverse step")
+        self._update(s)
         check(self.lib.dm_advance_counter(self.counter.data_ptr(), 1, s), "advance_counter")
 
     def _drop_graph(self):
@@ -277,3 +287,32 @@ class StepLoop:
             for t in trace:
                 t.record_stream(caller)
         return result
+
+
+class KStepLoop(StepLoop):
+    """The K-sampler loop of ``scripts/inference.py:293-318`` as a captured step graph: per step the latent is scaled by
+    ``get_input_scale()`` (and repeated for classifier-free guidance), the model runs, the two halves are combined and the
+    sampler's Euler update (with the ancestral noise term, if any) is applied - two small launches around the model's,
+    their scalars read from device tables by the step counter."""
+
+    def __init__(self, model, shape, device, sk, timesteps, scales, coefs, n_noise: int, cfg_scale: float, do_cfg: bool):
+        coef = torch.zeros(len(timesteps), 5)  # the base class's table slot is unused here
+        super().__init__(model, shape, device, sk, timesteps=timesteps, coef=coef, step="dm_ddpm_step", clip=False,
+                         n_noise=n_noise)
+        copies = 2 if do_cfg else 1
+        f32 = dict(dtype=torch.float32, device=device)
+        self.copies, self.cfg_scale, self.do_cfg = copies, float(cfg_scale), int(bool(do_cfg))
+        self.model_in = torch.empty((copies * shape[0],) + tuple(shape[1:]), **f32)
+        self.model_out = torch.empty_like(self.model_in)
+        self.scales = torch.tensor(scales, dtype=torch.float64).to(torch.float32).to(device)
+        self.kcoef = torch.tensor(coefs, dtype=torch.float64).to(torch.float32).contiguous().to(device)
+
+    def _pre(self, s):
+        check(self.lib.dm_ksampler_input(self.x.data_ptr(), self.model_in.data_ptr(), self.x.numel(), self.copies,
+                                         self.scales.data_ptr(), self.counter.data_ptr(), s), "ksampler_input")
+
+    def _update(self, s):
+        check(self.lib.dm_ksampler_step(self.x.data_ptr(), self.model_out.data_ptr(),
+                                        self.noise.data_ptr() if self.n_noise else None, self.x.data_ptr(), self.x.numel(),
+                                        self.kcoef.data_ptr(), self.counter.data_ptr(), self.cfg_scale, self.do_cfg, s),
+              "ksampler_step")

@@ -234,6 +234,18 @@ int dm_scale_add(const float* x, const float* y, float* out, int batch, long per
 int dm_axpbypcz(const float* x, float alpha, const float* y, float beta, const float* z, float gamma, float* out,
                 long n, hipStream_t stream);
 
+/* K-sampler loop body with the per-step scalars in DEVICE tables indexed by *step_index (one captured graph serves
+ * every step).  dm_ksampler_input: out[c][i] = scale_table[s] * x[i] for c < copies - the model input
+ * latents * sampler.get_input_scale(), repeated for classifier-free guidance (scripts/inference.py:300-304).
+ * dm_ksampler_step: guided = cfg_scale * (cond - uncond) + uncond with eps = [cond | uncond] when do_cfg
+ * (inference.py:313-315), else guided = eps; out = x + coef[2s] * guided (+ coef[2s+1] * noise[s*n ..] when that
+ * coefficient is non-zero): KEulerSampler.step (src/sampling/k_euler.py:78-111) and KEulerAncestralSampler.step
+ * (src/sampling/k_euler_ancestral.py:80-127).  Separately rounded fp32 operations in the eager path's order. */
+int dm_ksampler_input(const float* x, float* out, long n, int copies, const float* scale_table, const int* step_index,
+                      hipStream_t stream);
+int dm_ksampler_step(const float* x, const float* eps, const float* noise, float* out, long n, const float* coef,
+                     const int* step_index, float cfg_scale, int do_cfg, hipStream_t stream);
+
 /* out[(b, s)][:] = table[tokens[b][s]][:] + pos[s][:] in the engine dtype.  Replaces CLIPEmbedding.forward
  * (src/models/clip.py:52-57): nn.Embedding lookup + learned positional add.  tokens: int64 [rows],
  * rows = batch*seq; table fp32 [vocab][dim]; pos fp32 [seq][dim]. */

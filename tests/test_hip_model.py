@@ -411,6 +411,41 @@ def test_cfg_denoise_loop_matches_oracle(model_f32, dev):
     assert max_rel(got, cur) < 1e-3
 
 
+def test_ksampler_graph_loop_is_bitwise_the_stepwise_loop(model_f32, dev):
+    """pipeline.denoise as a captured step graph (Euler and Euler-ancestral, with and without guidance, an img2img
+    start in the middle of the schedule) against the same loop run launch by launch: identical bits, and the
+    sampler's step counter / generator end up in the same state."""
+    from diffusion_model_amd import pipeline
+    from diffusion_model_amd.sampling import KEulerAncestralSampler, KEulerSampler
+    gen = torch.Generator().manual_seed(21)
+    ctx2 = torch.randn(2, 77, 768, generator=gen).to(dev)
+    lat = torch.randn(1, 4, 16, 16, generator=gen).to(dev)
+    cases = [(KEulerSampler, True, None), (KEulerSampler, False, None), (KEulerAncestralSampler, True, None),
+             (KEulerAncestralSampler, True, 0.5)]
+    for cls, cfg, strength in cases:
+        outs, counts, states = [], [], []
+        # capture + replay first (its eager step settles the tile choice of every shape, which fixes the fp32
+        # summation order), then a replay of the kept graph, then launch by launch on the same tiles
+        for graph in (True, True, False):
+            kw = dict(generator=torch.Generator().manual_seed(3)) if cls is KEulerAncestralSampler else {}
+            smp = cls(n_inference_steps=4, **kw)
+            x = lat * float(smp.initial_scale)
+            if strength is not None:
+                x = pipeline.img2img_latents(smp, lat, strength, torch.Generator().manual_seed(4))
+            if graph and outs:
+                smp.__dict__["_dm_loops"] = kept
+            out = pipeline.denoise(model_f32, smp, ctx2 if cfg else ctx2[:1], x, cfg_scale=5.0, do_cfg=cfg,
+                                   use_hip_graph=graph)
+            kept = smp.__dict__.get("_dm_loops", {})
+            outs.append(out)
+            counts.append(smp.step_count)
+            states.append(smp.generator.get_state() if smp.generator is not None else None)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (cls.__name__, cfg, strength)
+        assert counts[0] == counts[1] == counts[2] == 4
+        if states[0] is not None:
+            assert torch.equal(states[0], states[1])
+
+
 def test_ddim_sample_matches_oracle(model_f32, dev):
     """DDIM sampling through the captured step graph (and eagerly), deterministic and with eta > 0, against the
     oracle's loop with the same draws: x_T first, then one draw per step (the reference's generator order)."""
