@@ -30,7 +30,7 @@ TILE_DIMS.update({TILE_D256x64_S2: (256, 64), TILE_D128x64_S2: (128, 64), TILE_D
 ALL_TILES = tuple(TILE_DIMS)
 
 _ERR = {1: "invalid argument / unsupported shape", 2: "HIP launch error", 3: "misaligned pointer or stride",
-        4: "unsupported attention head dimension (kernels exist for 40, 64, 80, 160 and 512)",
+        4: "unsupported attention head dimension (kernels exist for 40, 64, 80 and 160; wider heads go through the GEMM route)",
         5: "problem too large for the fixed scratch buffer of this allocation-free entry point"}
 
 

@@ -441,8 +441,15 @@ template <typename T, int D> int attn_launch(const AttnArgs& a, int batch, hipSt
     if constexpr (D <= 80) {
         if (forced == 4) return attn_launch_qt<T, D, 4>(a, batch, s);
     }
-    // Measured on MI355X (bf16 batch 16 and fp32 batch 1, all four U-Net levels): 16 rows per wave wins
-    // everywhere; the extra waves per SIMD hide the softmax VALU work better than wider tiles reuse K.
+    // Measured on MI355X inside whole U-Net forwards (bf16 at batch 1 / 4 / 16, fp32 at batch 1, all four levels).
+    // fp32: 16 rows per wave wins or ties everywhere.  bf16: a 16-row wave reads 14 KB of K / V fragments from LDS per
+    // key tile for 14 MFMAs, and with four or five such waves per SIMD the LDS pipe, not the MFMA or exp rate, sets
+    // the pace; 32 rows per wave halve those bytes per row and win once there are enough blocks to keep every CU
+    // supplied (S = 4096, d = 40 at batch 16: 623 -> 480 us; S = 256, d = 160: 24.0 -> 20.1 us), and lose below
+    // that (batch 1, S = 4096: 61.8 -> 65.2 us).  64 rows per wave never beat 32.
+    if constexpr (sizeof(T) == 2) {
+        if (forced == 0 && (per64 >= 1024 || (per64 >= 512 && D >= 160))) return attn_launch_qt<T, D, 2>(a, batch, s);
+    }
     // Far fewer 64-row blocks than CUs and a long MFMA chain per key tile (fp32, wide heads): split the head
     // dimension over the waves instead (16 rows per block).  Measured at batch 1 fp32: d = 160, S = 256: 32.8 -> 23.1 us
     // (77 keys: 16.9 -> 13.0 us); d <= 80 and every bf16 shape are faster unsplit.

@@ -478,7 +478,7 @@ class Engine:
     _TUNE_LEGACY_SK = False  # split-K with a separate reduction launch: measured slower overall than the work-list
                              # form once GroupNorm / LayerNorm statistics ride in the GEMM epilogue
 
-    def _time_candidate(self, d: GemmDesc, reps: int = 6) -> Optional[float]:
+    def _time_candidate(self, d: GemmDesc, reps: int = int(os.environ.get("DM_TUNE_REPS", "6"))) -> Optional[float]:
         """Device time (ms) of one launch of ``d``.  The launches are captured into a hipGraph and the replay is
         timed, so host launch latency (which exceeds the run time of the small problems) is not measured;
         on the legacy default stream, where capture is not allowed, back-to-back launches are timed."""

@@ -206,3 +206,27 @@ def test_arena_scoping():
         a.alloc(1 << 14, 1 << 12, torch.float32)
     a.reset()
     assert a.mark() == 0 and a.peak > 0
+
+
+def test_shipped_tile_table_is_well_formed():
+    """The committed tile table parses, names known tiles and covers both arithmetic types of the benchmark
+    configurations (it fixes tile and work-list choices, hence the fp32 summation order, for every process)."""
+    import ast
+    import json
+    import os
+
+    from diffusion_model_amd import _lib
+
+    path = os.path.join(os.path.dirname(_lib.__file__), "tune_table.json")
+    with open(path) as f:
+        table = json.load(f)
+    assert set(table) == {"torch.float32", "torch.bfloat16"}
+    for dtype, rows in table.items():
+        assert len(rows) > 100
+        for key, (tile, split) in rows.items():
+            k = ast.literal_eval(key)
+            assert isinstance(k, tuple) and len(k) == 13 and k[0] > 0 and k[1] > 0 and k[2] > 0
+            assert tile in _lib.TILE_DIMS
+            assert split != 0
+            if tile == _lib.TILE_D256x256_S2:
+                assert dtype == "torch.bfloat16" and split <= 1
