@@ -27,9 +27,14 @@ def load(d, counter):
 
 
 def klass(name):
-    m = re.search(r"(conv3x3_igemm_kernel|gemm_dma_kernel|attn_kernel|gn_stats_kernel|gn_apply_kernel|layernorm_kernel|"
-                  r"splitk_reduce_kernel|linear_rows_kernel)", name)
-    return m.group(1) if m else None
+    """Kernel class of a dispatch; the two conv3x3 kernels (generic ring and 256x256 ping-pong tile) are one class, as are
+    the two dense GEMM kernels."""
+    m = re.search(r"(conv3x3_igemm_kernel|conv3x3_wide_kernel|gemm_dma_kernel|gemm_wide_kernel|attn_kernel|gn_stats_kernel|"
+                  r"gn_apply_kernel|layernorm_kernel|splitk_reduce_kernel|linear_rows_kernel)", name)
+    if not m:
+        return None
+    return {"conv3x3_igemm_kernel": "conv3x3", "conv3x3_wide_kernel": "conv3x3", "gemm_dma_kernel": "gemm",
+            "gemm_wide_kernel": "gemm"}.get(m.group(1), m.group(1))
 
 
 def last_forward(rows):
