@@ -324,14 +324,19 @@ def test_bf16_batch16_members_match_single_runs(model_f32, dev):
 def test_full_length_trajectory_64(model_f32, dev):
     """The benchmark workload itself: 50 DDPM steps at the 64x64 latent, batch 1, identical x_T / injected noise /
     context on both sides; every per-step latent against the CPU oracle.  fp32 bar: 1e-3 (asserted at 1e-4;
-    measured 1e-6).  bf16 stated tolerance: 3e-2 over the 50 steps (measured 1.4e-2 at the last step, growing by
-    about 3e-4 per step; 4.7e-4 after 5 steps, where the reference's own CPU bf16 path is at 3.7e-3)."""
+    measured 1e-6).  bf16, stated tolerance: 3e-2 over the 50 steps against the fp32 oracle (measured 1.5e-2 at the last
+    step).  Nearly all of that is the rounding of the WEIGHTS to bf16, which any bf16 run of the model shares: the fp32
+    oracle on bf16-rounded weights is itself 1.4e-2 away from the fp32 oracle.  What the device adds - bf16 activations
+    between kernels, bf16 MFMA operands - is asserted separately against that rounded-weight oracle at 1e-2 over the 50
+    steps (measured 2.9e-3)."""
     T = 50
     state = {k: v.cpu() for k, v in model_f32.state_dict().items()}
     ctx = torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(1))
     x_T, noises = sched_ref.draw_ddpm_noise((1, 4, 64, 64), T, torch.Generator().manual_seed(42))
-    want = []
+    want, want_rounded = [], []
     sched_ref.ddpm_sample(unet_ref.OracleDiffusion(state), sched_ref.make_tables(T), x_T, noises, ctx, trace=want)
+    rounded = {k: (v.bfloat16().float() if v.is_floating_point() else v) for k, v in state.items()}
+    sched_ref.ddpm_sample(unet_ref.OracleDiffusion(rounded), sched_ref.make_tables(T), x_T, noises, ctx, trace=want_rounded)
     m16 = Diffusion()
     m16.load_state_dict(model_f32.state_dict())
     m16 = m16.to(dev).bfloat16().eval()
@@ -341,6 +346,8 @@ def test_full_length_trajectory_64(model_f32, dev):
                                                                  trace=got)
         errs = [max_rel(g, w) for g, w in zip(got, want)]
         assert len(errs) == T and max(errs) < bar, (bar, max(errs), errs[::10])
+    errs = [max_rel(g, w) for g, w in zip(got, want_rounded)]  # `got` is the bf16 run
+    assert max(errs) < 1e-2, (max(errs), errs[::10])
     del m16
     torch.cuda.empty_cache()
 

@@ -2,7 +2,11 @@
 """Full-length trajectory parity: the T-step DDPM loop on the HIP path (fp32 and bf16 weights) against the CPU oracle
 with identical x_T, injected noise and context; prints the per-step latent max-rel error.
 
-    python tools/trajectory_parity.py [--steps 50] [--latent 64]
+    python tools/trajectory_parity.py [--steps 50] [--latent 64] [--decompose]
+
+--decompose also runs the fp32 oracle on weights rounded to bf16 and prints the bf16 error split into its two sources:
+the rounding of the weights (rounded-weight oracle against the oracle) and everything that happens to activations on
+the device - bf16 storage between kernels, bf16 MFMA operands - (HIP bf16 against the rounded-weight oracle).
 """
 import argparse
 import os
@@ -20,6 +24,7 @@ from oracle import sched_ref, unet_ref  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--latent", type=int, default=64)
+ap.add_argument("--decompose", action="store_true")
 args = ap.parse_args()
 T, HW = args.steps, args.latent
 dev = torch.device("cuda", 0)
@@ -51,3 +56,16 @@ for name, m in (("fp32", model), ("bf16", None)):
     errs = [rel(g, w) for g, w in zip(got, want)]
     print(f"{name}: max over steps {max(errs):.3e}, final {errs[-1]:.3e}; every 5th step: "
           + " ".join(f"{e:.1e}" for e in errs[4::5]), flush=True)
+    if name == "bf16":
+        got_bf16 = got
+
+if args.decompose:
+    rounded = {k: (v.bfloat16().float() if v.is_floating_point() else v) for k, v in state.items()}
+    mid = []
+    sched_ref.ddpm_sample(unet_ref.OracleDiffusion(rounded), sched_ref.make_tables(T), x_T, noises, ctx, trace=mid)
+    e_w = [rel(m_, w) for m_, w in zip(mid, want)]
+    e_a = [rel(g, m_) for g, m_ in zip(got_bf16, mid)]
+    print("bf16 sources - weights rounded to bf16, fp32 arithmetic (oracle vs oracle): every 5th step: "
+          + " ".join(f"{e:.1e}" for e in e_w[4::5]), flush=True)
+    print("bf16 sources - device activations (HIP bf16 vs rounded-weight oracle):     every 5th step: "
+          + " ".join(f"{e:.1e}" for e in e_a[4::5]), flush=True)
