@@ -41,6 +41,23 @@ def _compile(src):
     return obj
 
 
+def build_timeline() -> str:
+    """Diagnostic variant libdm_hip_tl.so: the generic GEMM / conv kernel stamps a wall clock at its phase boundaries
+    (tools/timeline_gemm.py loads it through DM_HIP_LIBRARY).  Not shipped, not loaded by the package."""
+    obj_dir = os.path.join(CSRC, "build_tl")
+    os.makedirs(obj_dir, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
+        if _stale(obj, [os.path.join(CSRC, src), *HEADERS]):
+            subprocess.run(["hipcc", *FLAGS, "-DDM_TIMELINE", *EXTRA.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj],
+                           check=True)
+        objs.append(obj)
+    lib = os.path.join(CSRC, "libdm_hip_tl.so")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], check=True)
+    return lib
+
+
 def build(force: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
@@ -54,4 +71,4 @@ def build(force: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build_timeline() if "--timeline" in sys.argv else build(force="--force" in sys.argv))

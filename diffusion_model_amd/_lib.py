@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdm_hip.so")
+# DM_HIP_LIBRARY=<path>: load another build of the same ABI (the diagnostic timeline build of `python build.py --timeline`)
+LIB_PATH = os.environ.get("DM_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libdm_hip.so")
 
 DM_F32, DM_BF16 = 0, 1
 EPI_PLAIN, EPI_GEGLU, EPI_NCHW_F32, EPI_QUICKGELU = 0, 1, 2, 3

@@ -69,6 +69,34 @@ struct GemmArgs {
 // source of every lane whose 16 bytes must read as zero in the direct-to-LDS loop
 __device__ __attribute__((aligned(16))) uint32_t g_zero16[4];
 
+// Diagnostic build only (python build.py --timeline -> libdm_hip_tl.so, read with tools/timeline_gemm.py): thread 0 of
+// every block of the generic kernel stamps the 100 MHz wall clock at the phase boundaries of its first two work-list
+// segments.  The shipped library compiles none of this.
+#ifdef DM_TIMELINE
+constexpr int TL_BLOCKS = 4096, TL_SLOTS = 16;
+__device__ unsigned long long g_timeline[TL_BLOCKS * TL_SLOTS];
+#define DM_TL(seg, i)                                                                            \
+    do {                                                                                          \
+        if (threadIdx.x == 0 && blockIdx.x < TL_BLOCKS && (seg) < 2)                              \
+            g_timeline[blockIdx.x * TL_SLOTS + (seg) * 8 + (i)] = wall_clock64();                 \
+    } while (0)
+#define DM_TL_CYCLES_BEGIN() tl_cycles = clock64()
+#define DM_TL_CYCLES_END(seg)                                                                     \
+    do {                                                                                          \
+        if (threadIdx.x == 0 && blockIdx.x < TL_BLOCKS && (seg) < 2)                              \
+            g_timeline[blockIdx.x * TL_SLOTS + (seg) * 8 + 7] = clock64() - tl_cycles;            \
+    } while (0)
+// Knock-out switches of the diagnostic build (dm_timeline_variant): bit 1 = no DMA issue inside the k loop, bit 2 = no
+// waits / barrier after the first k-tile.  Results are garbage; only durations are of interest.
+__device__ int g_tl_variant;
+#define DM_TL_ON(bit) (!(tl_variant & (bit)))
+#else
+#define DM_TL(seg, i) do { } while (0)
+#define DM_TL_ON(bit) true
+#define DM_TL_CYCLES_BEGIN() do { } while (0)
+#define DM_TL_CYCLES_END(seg) do { } while (0)
+#endif
+
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // Byte offset of packed weight row `row`, k-tile `kt`, in the blocked image [Npad/64][nkt][64][128 B];
@@ -561,6 +589,11 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
     // its run segment by segment (at most one tile entered late and one left early).
     long u = 0, u_end = 1;
     int sk_g = 0;
+    [[maybe_unused]] int tl_seg = -1;
+    [[maybe_unused]] unsigned long long tl_cycles = 0;  // shader-clock count at the start of the k loop (diagnostic build)
+#ifdef DM_TIMELINE
+    const int tl_variant = __builtin_amdgcn_readfirstlane(g_tl_variant);
+#endif
     if (p.streamk) {
         sk_g = xcd_remap(blockIdx.x, gridDim.x);
         const long U = (long)ntm * ntn * nkt;
@@ -591,6 +624,8 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
         const int tile_m = m_fast ? tile_id % ntm : tile_id / ntn;
         const int tile_n = m_fast ? tile_id / ntm : tile_id - tile_m * ntn;
         const int m0 = tile_m * BM, n0 = tile_n * BN;
+        ++tl_seg;
+        DM_TL(tl_seg, 0);  // segment entered
 
         ARows<A_IT> rows;
         init_rows<A_IT, NT / 8>(rows, p, m0, tid >> 3, BM);
@@ -738,6 +773,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
             }
         } else {
         // prologue: up to STAGES-1 tiles in flight
+        DM_TL(tl_seg, 1);  // pointers set up, first request about to go out
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
             if (kt0 + s < kt1) issue(kt0 + s, s);
@@ -747,17 +783,25 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
             // tile kt has landed once only the younger tiles in flight (at most STAGES-2, fewer at the end
             // of the run) are outstanding; the barrier makes every wave's share visible and retires all
             // reads of the stage refilled below
-            wait_young<LOADS, STAGES - 2>(kt1 - 1 - kt);
-            __builtin_amdgcn_s_barrier();
+            if (DM_TL_ON(2) || kt == kt0) {
+                wait_young<LOADS, STAGES - 2>(kt1 - 1 - kt);
+                __builtin_amdgcn_s_barrier();
+            }
+            if (kt == kt0) {
+                DM_TL(tl_seg, 2);  // first k-tile landed
+                DM_TL_CYCLES_BEGIN();
+            }
             int nstage = stage + STAGES - 1;
             if (nstage >= STAGES) nstage -= STAGES;
-            if (kt + STAGES - 1 < kt1) issue(kt + STAGES - 1, nstage);
+            if (DM_TL_ON(1) && kt + STAGES - 1 < kt1) issue(kt + STAGES - 1, nstage);
             const char* sa = smem + stage * STAGE_BYTES;
             mma_tile<T, FM>(acc, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq);
             if (++stage == STAGES) stage = 0;
         }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DM_TL(tl_seg, 3);  // k loop done
+        DM_TL_CYCLES_END(tl_seg);
 
         if (p.streamk && !(kt0 == 0 && kt1 == nkt)) {
             // Partial tile.  Every block that holds a k-run of this tile stores its accumulators, in
@@ -787,6 +831,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
                 *ticket = __hip_atomic_fetch_add(p.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             const bool last = *ticket == g_last - g_first;
+            DM_TL(tl_seg, 4);  // slab stored, ticket drawn
             if (!last) continue;
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -794,18 +839,59 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
                 __hip_atomic_store(p.counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
-            for (int c = g_first; c <= g_last; ++c) {
-                const float* slab = p.slabs + (2L * c + (c == g_first ? 1 : 0)) * SLAB;
+            // A deep split leaves a dozen slabs per tile; read one after the other, each costs an exposed memory latency
+            // and the sum lasts as long as the k loop.  The LDS ring is idle now: as many slabs as fit are requested into
+            // it at once by the DMA path (no registers), then added in block order.  Every thread reads back exactly
+            // the 16-byte pieces its own DMA lanes wrote, so draining vmcnt is the only synchronisation.
+            constexpr int SLAB_BYTES = BM * BN * 4;
+            constexpr int SLABS_IN_LDS = STAGES * STAGE_BYTES / SLAB_BYTES;
+            if constexpr (SLABS_IN_LDS >= 2) {
+                for (int c0s = g_first; c0s <= g_last; c0s += SLABS_IN_LDS) {
 #pragma unroll
-                for (int i = 0; i < FM; ++i)
+                    for (int u = 0; u < SLABS_IN_LDS; ++u) {
+                        const int c = c0s + u;
+                        if (c <= g_last) {  // block-uniform
+                            const char* src = reinterpret_cast<const char*>(p.slabs + (2L * c + (c == g_first ? 1 : 0)) * SLAB) + tid * 16;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(slab + ((i * 4 + j) * NT + tid) * 4);
-                        acc[i][j] = c == g_first ? v : acc[i][j] + v;
+                            for (int e = 0; e < FM * 4; ++e)
+                                __builtin_amdgcn_global_load_lds(
+                                    (const __attribute__((address_space(1))) void*)(src + e * (NT * 16)),
+                                    (__attribute__((address_space(3))) void*)(smem + u * SLAB_BYTES + e * (NT * 16) + lds_wave), 16, 0, 0);
+                        }
                     }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int u = 0; u < SLABS_IN_LDS; ++u) {
+                        const int c = c0s + u;
+                        if (c <= g_last) {
+#pragma unroll
+                            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const f32x4 v = *reinterpret_cast<const f32x4*>(smem + u * SLAB_BYTES + ((i * 4 + j) * NT + tid) * 16);
+                                    acc[i][j] = c == g_first ? v : acc[i][j] + v;
+                                }
+                        }
+                    }
+                    // the reads above are complete (their values were added) before the next round's DMA is issued
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            } else {
+                for (int c = g_first; c <= g_last; ++c) {
+                    const float* slab = p.slabs + (2L * c + (c == g_first ? 1 : 0)) * SLAB;
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(slab + ((i * 4 + j) * NT + tid) * 4);
+                            acc[i][j] = c == g_first ? v : acc[i][j] + v;
+                        }
+                }
             }
         }
+        DM_TL(tl_seg, 5);  // (last holder of a split tile: slabs summed) epilogue starts
         epilogue<T, FM>(p, acc, m0 + wm * 16 * FM, n0 + wn * 64, fr, fq, blockIdx.y, ln_mu, ln_rs, ln_cs);
+        DM_TL(tl_seg, 6);  // epilogue issued
     }
 }
 // Waves per SIMD that the LDS ring lets a CU hold (capped at 4): the register budget the compiler must
@@ -1685,3 +1771,19 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     }
     return rc;
 }
+
+#ifdef DM_TIMELINE
+extern "C" int dm_timeline_variant(int bits) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tl_variant), &bits, sizeof(int)) == hipSuccess ? DM_OK : DM_ERR_LAUNCH;
+}
+// Diagnostic build: copies the phase stamps of the last launch to the host and clears them.
+extern "C" int dm_timeline_read(unsigned long long* host, int blocks) {
+    if (!host || blocks <= 0 || blocks > TL_BLOCKS) return DM_ERR_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return DM_ERR_LAUNCH;
+    const size_t bytes = (size_t)blocks * TL_SLOTS * sizeof(unsigned long long);
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_timeline), bytes) != hipSuccess) return DM_ERR_LAUNCH;
+    void* dev = nullptr;
+    if (hipGetSymbolAddress(&dev, HIP_SYMBOL(g_timeline)) != hipSuccess) return DM_ERR_LAUNCH;
+    return hipMemset(dev, 0, sizeof(unsigned long long) * TL_BLOCKS * TL_SLOTS) == hipSuccess ? DM_OK : DM_ERR_LAUNCH;
+}
+#endif
