@@ -87,7 +87,7 @@ __device__ unsigned long long g_timeline[TL_BLOCKS * TL_SLOTS];
             g_timeline[blockIdx.x * TL_SLOTS + (seg) * 8 + 7] = clock64() - tl_cycles;            \
     } while (0)
 // Knock-out switches of the diagnostic build (dm_timeline_variant): bit 1 = no DMA issue inside the k loop, bit 2 = no
-// waits / barrier after the first k-tile.  Results are garbage; only durations are of interest.
+// waits / barrier after the first k-tile, bit 8 = no epilogue at all.  Results are garbage; only durations are of interest.
 __device__ int g_tl_variant;
 #define DM_TL_ON(bit) (!(tl_variant & (bit)))
 #else
@@ -890,7 +890,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
             }
         }
         DM_TL(tl_seg, 5);  // (last holder of a split tile: slabs summed) epilogue starts
-        epilogue<T, FM>(p, acc, m0 + wm * 16 * FM, n0 + wn * 64, fr, fq, blockIdx.y, ln_mu, ln_rs, ln_cs);
+        if (DM_TL_ON(8)) epilogue<T, FM>(p, acc, m0 + wm * 16 * FM, n0 + wn * 64, fr, fq, blockIdx.y, ln_mu, ln_rs, ln_cs);
         DM_TL(tl_seg, 6);  // epilogue issued
     }
 }
