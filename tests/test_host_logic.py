@@ -75,6 +75,14 @@ def test_null_arguments_are_rejected_without_a_device():
     assert handle.dm_ddpm_step(None, None, None, None, 16, None, None, 1, None) == 1
     assert handle.dm_attention(None, 0, None, 0, None, 0, None, 0, 1, 8, 64, 64, 40, 0, 0, None) == 1
     assert handle.dm_groupnorm_stats(None, 0, 1, 64, 320, 32, 0, None, 1, None) == 1
+    # the entry points added later reject null pointers / empty problems the same way, before touching a device
+    assert handle.dm_groupnorm_noalloc(None, 0, None, 0, 1, 64, 320, 32, 0, None, None, 1e-5, 1, None) == 1
+    assert handle.dm_softmax_rows(None, 0, 4, 64, 1.0, 0, None) == 1
+    assert handle.dm_pack_rows(None, 0, 64, 64, 0, None, 64, 64, 0, None) == 1
+    assert handle.dm_vae_sample(None, None, None, 1, 64, 0.18215, None) == 1
+    assert handle.dm_ksampler_input(None, None, 16, 2, None, None, None) == 1
+    assert handle.dm_ksampler_step(None, None, None, None, 16, None, None, 7.5, 1, None) == 1
+    assert handle.dm_groupnorm_default_nsplit(1, 4096) >= 1
 
 
 # ------------------------------------------------------------------------------------------- schedules
