@@ -101,6 +101,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     // When D leaves spare rows in the last 16-row tile of O^T, column D of the V tile is fed with ones so
     // that the second product also delivers sum_k P[q][k] (in O^T row D) and the VALU never adds the row sum.
     constexpr bool ONES = !DSPLIT && (D % 16) != 0;
+    // fp32, head dim = 8 mod 16 (d = 40): the last 64-byte k-step of K Q^T holds 8 real values and 8 of padding, and
+    // with the usual layout (lane group qp owns chunk qp) each of its four 16x16x4 MFMAs multiplies half padding.
+    // Here lane group qp owns the two values 2*qp, 2*qp + 1 of that step instead (the same permutation of k on both
+    // operands), so two MFMAs cover it: 20 instead of 24 per 16 keys.
+    constexpr bool HALF_LAST = sizeof(T) == 4 && !DSPLIT && (D % 16) == 8;
     constexpr int PBUF = 4 * NKT * 64 * 16;  // DSPLIT: one buffer of partial score tiles (4 waves x NKT x 64 lanes x 16 B)
     auto ksw = [](int row) { return (row >> 1) & 3; };
     static_assert(D % EPC == 0, "head dim must be a whole number of 16-byte chunks");
@@ -192,7 +197,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         for (int ks = 0; ks < NKS; ++ks) {
             const int ch = ks * 4 + qp;
             const long e = ((long)b * p.sq + row) * p.ldq + (long)h * D + ch * EPC;
-            const u32x4 raw = ldg16(p.q + e * ESZ, row < p.sq && ch < DCH);
+            u32x4 raw;
+            if (HALF_LAST && ks == NKS - 1) {
+                const long e2 = ((long)b * p.sq + row) * p.ldq + (long)h * D + ks * 16 + 2 * qp;
+                u32x2 two = {0u, 0u};
+                if (row < p.sq) two = *reinterpret_cast<const u32x2*>(p.q + e2 * ESZ);
+                raw = u32x4{two[0], two[1], 0u, 0u};
+            } else {
+                raw = ldg16(p.q + e * ESZ, row < p.sq && ch < DCH);
+            }
             float f[EPC];
             chunk_to_f32<T>(raw, f);
 #pragma unroll
@@ -232,8 +245,26 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
                 const int row = key_of(kt, c);
-                dst[kt] = *reinterpret_cast<const u32x4*>(s_k + ks * K_SLAB + row * 64 + ((qp ^ ksw(row)) << 4));
+                if (HALF_LAST && ks == NKS - 1) {
+                    const u32x2 two = *reinterpret_cast<const u32x2*>(s_k + ks * K_SLAB + row * 64 +
+                                                                      (((qp >> 1) ^ ksw(row)) << 4) + (qp & 1) * 8);
+                    dst[kt] = u32x4{two[0], two[1], 0u, 0u};
+                } else {
+                    dst[kt] = *reinterpret_cast<const u32x4*>(s_k + ks * K_SLAB + row * 64 + ((qp ^ ksw(row)) << 4));
+                }
             }
+        };
+        // one k-step of K Q^T for one (key block, query tile)
+        auto mma_ks = [&](f32x4& acc, const u32x4& kfrag, const u32x4& qfrag, int ks) {
+            if constexpr (HALF_LAST) {
+                if (ks == NKS - 1) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(kfrag[e]), __uint_as_float(qfrag[e]), acc, 0, 0, 0);
+                    return;
+                }
+            }
+            Mma16<T>::mma(acc, kfrag, qfrag);
         };
         if constexpr (DSPLIT) {
             const float start = wv == 0 ? -m_ref[0] : 0.f;  // the shift is added once, by wave 0's partial
@@ -273,7 +304,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) Mma16<T>::mma(sacc[kt][qt], kf[ks & 1][kt], qf[qt][ks]);
+                    for (int qt = 0; qt < QT; ++qt) mma_ks(sacc[kt][qt], kf[ks & 1][kt], qf[qt][ks], ks);
             }
         }
         // ---- softmax numerators; lane holds keys t*KT + key_of(kt, 4*qp + r) of query row c
