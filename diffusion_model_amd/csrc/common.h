@@ -109,18 +109,21 @@ template <> struct Mma16<float> {
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// GELU(erf) for outputs that are rounded to bf16: erf by Abramowitz-Stegun 7.1.26 (|error| < 2e-7,
-// far below half a bf16 ulp), one rcp + one exp2 + six FMAs instead of the branchy libm erff.
+// GELU(erf) for outputs that are rounded to bf16: erf by Abramowitz-Stegun 7.1.25 (three terms, |error| <= 2.5e-5: the
+// result is off by at most 1.3e-5 |x|, against a bf16 half-ulp of 2e-3 |result|), one rcp + one exp2 and eleven
+// instructions in all instead of the branchy libm erff.  The GEGLU epilogue evaluates 84 million of these per forward
+// at batch 16 and is bound by VALU issue.  With w = |x| sqrt(log2(e) / 2): exp(-x^2 / 2) = exp2(-w^2), and the
+// rational argument 1 / (1 + p |x| / sqrt 2) becomes 1 / (1 + p' w).
 __device__ __forceinline__ float gelu_erf_fast_f(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
-    const float erf_abs = fmaf(-poly * t, e, 1.0f);  // erf(|x| / sqrt 2)
-    return 0.5f * x + 0.5f * fabsf(x) * erf_abs;     // 0.5 x (1 + sign(x) erf_abs)
+    const float w = fabsf(x) * 0.84932180028801904272f;                      // sqrt(log2(e) / 2)
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.39168235197889934f, w, 1.0f));  // 0.47047 / sqrt(log2 e)
+    float poly = fmaf(0.7478556f, t, -0.0958798f);
+    poly = fmaf(poly, t, 0.3480242f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-(w * w));
+    const float erf_abs = fmaf(-poly, e, 1.0f);  // erf(|x| / sqrt 2)
+    const float h = 0.5f * x;
+    return fmaf(fabsf(h), erf_abs, h);           // 0.5 x (1 + sign(x) erf_abs)
 }
 
 // 16-byte global load with a zero default (predicated-off lanes read nothing).
