@@ -17,6 +17,7 @@ import re
 import sys
 
 fdir, wdir, out, label = sys.argv[1:5]
+order_file = sys.argv[5] if len(sys.argv) > 5 else None  # launch order written by prof_forward.py --dump-order
 
 
 def load(d, counter):
@@ -62,6 +63,33 @@ for k, v in res.items():
     tot = v["fetch_bytes"] + v["write_bytes"]
     summary["per_forward"][k] = {"launches": v["launches"], "fetch": v["fetch_bytes"], "write": v["write_bytes"], "total": tot}
     summary["per_launch"][k] = tot / max(v["launches"], 1)
+if order_file:
+    # conv3x3 traffic by layer shape: the i-th conv dispatch of the forward is the i-th conv launch the engine recorded
+    tags = json.load(open(order_file)).get("conv3x3", [])
+    fe = [float(r["Counter_Value"]) * 2048 for r in last_forward(load(fdir, "FETCH_SIZE")) if klass(r["Kernel_Name"]) == "conv3x3"]
+    wr = [float(r["Counter_Value"]) * 1024 for r in last_forward(load(wdir, "WRITE_SIZE")) if klass(r["Kernel_Name"]) == "conv3x3"]
+    if len(tags) == len(fe) == len(wr):
+        esz = 2 if "bf16" in label else 4
+        by = collections.OrderedDict()
+        for tag, f_, w_ in zip(tags, fe, wr):
+            kv = dict(t.split("=") for t in tag.split())
+            m, n, k = int(kv["m"]), int(kv["n"]), int(kv["k"])
+            rows_in = m // 4 if kv.get("up") == "1" else m * (4 if kv.get("s") == "2" else 1)
+            alg = (rows_in * (k // 9) + n * k + m * n) * esz  # input once + weights once + output once (folded 1x1 terms ignored)
+            key = " ".join(f"{a}={kv[a]}" for a in ("m", "n", "k", "s", "up"))
+            d = by.setdefault(key, {"launches": 0, "fetch": 0.0, "write": 0.0, "algorithmic": 0.0})
+            d["launches"] += 1
+            d["fetch"] += f_
+            d["write"] += w_
+            d["algorithmic"] += alg
+        summary["conv3x3_by_shape"] = by
+        print("conv3x3 by shape (MB per launch): fetch, write, algorithmic, ratio")
+        for key, d in sorted(by.items(), key=lambda kv: -(kv[1]["fetch"] + kv[1]["write"])):
+            L = d["launches"]
+            print(f"  {key:44s} x{L}  {d['fetch']/L/1e6:8.1f} {d['write']/L/1e6:7.1f} {d['algorithmic']/L/1e6:8.1f}  "
+                  f"{(d['fetch'] + d['write']) / d['algorithmic']:5.2f}")
+    else:
+        print(f"launch order has {len(tags)} convs, the counter passes {len(fe)} / {len(wr)}: no per-shape table")
 json.dump(summary, open(out, "w"), indent=1)
 for k, v in sorted(summary["per_forward"].items(), key=lambda kv: -kv[1]["total"]):
     print(f"{k:24s} x{v['launches']:3d}  fetch {v['fetch']/1e6:9.1f} MB  write {v['write']/1e6:9.1f} MB  per launch {summary['per_launch'][k]/1e6:8.2f} MB")

@@ -16,6 +16,7 @@ from diffusion_model_amd.schedulers.base_scheduler import sinusoidal_table  # no
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", type=int, default=2)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--dump-order", default="", help="write the launch order of the last forward (class -> list of shape tags) here")
 args = ap.parse_args()
 cfg = bench.CONFIGS[args.config]
 dev = torch.device("cuda", 0)
@@ -24,7 +25,14 @@ B, HW = cfg["batch"], cfg["latent"]
 ctx = torch.randn(B, 77, 768, generator=torch.Generator().manual_seed(1)).to(dev)
 x = torch.randn(B, 4, HW, HW, device=dev)
 temb = sinusoidal_table(torch.full((B,), 25), 320).to(dev)
-for _ in range(args.reps):
+for rep in range(args.reps):
+    if args.dump_order and rep == args.reps - 1:
+        eng, _ = model.hip_pack(dev)
+        eng.profile = {}
     out = model(x, ctx, temb)
 torch.cuda.synchronize()
+if args.dump_order:
+    import json
+    with open(args.dump_order, "w") as f:
+        json.dump({k: [rec[3] for rec in v] for k, v in eng.profile.items()}, f)
 print("ok", float(out.abs().mean()))
