@@ -57,6 +57,8 @@ class GemmDesc(C.Structure):
         ("ln_in", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_out", C.c_void_p),
         ("a2", C.c_void_p), ("lda2", C.c_long), ("cin2", C.c_int),
         ("pad_hi_only", C.c_int),
+        ("gn_sums", C.c_void_p), ("ld_gn", C.c_long), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
+        ("gn_eps", C.c_float), ("gn_silu", C.c_int), ("gn_groups", C.c_int),
     ]
 
 
@@ -68,6 +70,7 @@ _PROTOS = {
     "dm_gemm_workspace_bytes": (C.c_long, [_i, _i, _i]),
     "dm_gemm_streamk_workspace_bytes": (C.c_long, [_i, _i, _i, _i]),
     "dm_gemm_stats_supported": (C.c_int, [_i, _i, _i]),
+    "dm_gemm_gn_supported": (C.c_int, [_i, _i, _i, _i, _i, _i, _i]),
     "dm_groupnorm_apply_sums": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _f, _i, _vp]),
     "dm_zero": (C.c_int, [_vp, _l, _vp]),
     "dm_pack_weight_order": (C.c_int, [_i, _i, _i, _vp]),
@@ -129,7 +132,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dm_abi_version() != 7:
+        if handle.dm_abi_version() != 8:
             raise RuntimeError("libdm_hip.so ABI version mismatch; rebuild with `python build.py`")
         _lib = handle
     return _lib

@@ -64,6 +64,14 @@ struct GemmArgs {
     int streamk;    // stream-K: number of blocks sharing the (tile, k-tile) work list; 0 = one tile per block
     int* counters;  // stream-K: one arrival counter per output tile, zero on entry, left zero
     float* slabs;   // stream-K: 2 accumulator slabs per block
+    // GroupNorm (+ SiLU) of the A operand applied to the fragments in registers (fp32, GN kernels only)
+    const double* gn_sums;  // per-channel (sum, sumsq) of A, [batch][2][ld_gn]
+    long ld_gn;
+    const float* gn_gamma;
+    const float* gn_beta;
+    float gn_eps;
+    int gn_groups;
+    int gn_c;       // channels that are normalised: Cin (conv) or K - Cin2 (dense)
 };
 
 // source of every lane whose 16 bytes must read as zero in the direct-to-LDS loop
@@ -249,6 +257,154 @@ __device__ __forceinline__ void mfma_tile_frags(f32x4 (&acc)[FM][4], const u32x4
 #pragma unroll
                 for (int j = 0; j < 4; ++j) Mma16<T>::mma(acc[i][j], wf[ks][j], af[ks][i]);
         }
+    }
+}
+
+// ---- GroupNorm of the A operand inside the GEMM (fp32) ----------------------------------------------
+// The tensor a GroupNorm reads has exactly one consumer here (the convolution or 1x1 projection behind it), and
+// its per-channel sums already exist (the launch that wrote it accumulated them).  Instead of a launch that
+// reads the tensor, normalises it and writes it back, the consumer normalises its A fragments on their way from
+// LDS to the MFMA: y = x * scale[c] + shift[c] (+ SiLU), scale = rstd * gamma, shift = beta - mean * scale.  With the
+// exact-fp32 MFMA (32 cycles for 4 k values of a 16 x 16 tile) a lane has one A register per four MFMAs, so the
+// extra VALU work hides behind the matrix pipe; with bf16 operands it would not (eight values per register, 16-cycle
+// MFMAs), which is why only the fp32 kernels have this form.
+//
+// Scale / shift of the sample's C channels live in LDS behind the operand ring: scale[C] | shift[C] | scratch.
+constexpr int GN_FUSE_MAX_C = 1280;
+constexpr int GN_FUSE_SCRATCH = 64 * 8 * 2 * 8 + 2 * 64 * 4;  // partial sums (fp64) + group mean / rstd
+__host__ __device__ constexpr int gn_fuse_lds_bytes(int c) { return 2 * c * 4 + GN_FUSE_SCRATCH; }
+
+// Same arithmetic, in the same order, as gn_apply_kernel's statistics fold (norm.hip): 8 strided fp64 partial sums
+// per group, added in order; mean and variance in fp64.
+template <int NT>
+__device__ __forceinline__ void gn_build_table(const GemmArgs& p, int b, float* tab) {
+    const int c = p.gn_c, groups = p.gn_groups, cpg = c / groups;
+    float* t_scale = tab;
+    float* t_shift = tab + c;
+    double* sub = reinterpret_cast<double*>(tab + 2 * c);       // [groups][8][2]
+    float* g_mean = reinterpret_cast<float*>(sub + 64 * 8 * 2);  // [64]
+    float* g_rstd = g_mean + 64;
+    const int tid = threadIdx.x;
+    // affine parameters of this thread's channels, requested now: their latency overlaps the statistics fold
+    constexpr int CH = (GN_FUSE_MAX_C + NT - 1) / NT;
+    float gam[CH], bet[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int ch = tid + k * NT;
+        gam[k] = ch < c ? p.gn_gamma[ch] : 0.f;
+        bet[k] = ch < c ? p.gn_beta[ch] : 0.f;
+    }
+    const double* src = p.gn_sums + (long)b * 2 * p.ld_gn;
+    for (int item = tid; item < groups * 8; item += NT) {
+        const int grp = item >> 3, part = item & 7;
+        double a = 0.0, d = 0.0;
+        for (int ch = grp * cpg + part; ch < (grp + 1) * cpg; ch += 8) {
+            a += src[ch];
+            d += src[p.ld_gn + ch];
+        }
+        sub[item * 2] = a;
+        sub[item * 2 + 1] = d;
+    }
+    __syncthreads();
+    for (int grp = tid; grp < groups; grp += NT) {
+        double a = 0.0, d = 0.0;
+        for (int part = 0; part < 8; ++part) {
+            a += sub[(grp * 8 + part) * 2];
+            d += sub[(grp * 8 + part) * 2 + 1];
+        }
+        const double n = (double)p.rows_per_batch * cpg;
+        const double mean = a / n;
+        double var = d / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        g_mean[grp] = (float)mean;
+        g_rstd[grp] = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int ch = tid + k * NT;
+        if (ch < c) {
+            const int grp = ch / cpg;
+            const float sc = g_rstd[grp] * gam[k];
+            t_scale[ch] = sc;
+            t_shift[ch] = fmaf(-g_mean[grp], sc, bet[k]);
+        }
+    }
+    __syncthreads();
+}
+
+// One k-tile of fp32 MFMAs with the A fragments normalised on the way.  ts / tt: scale / shift of the k-tile's first
+// channel; vmask[i] bit `bit`: row i of this lane reads real data in this k-tile (a padding tap or a row past M must
+// stay zero AFTER the affine map); raw: the k-tile belongs to the appended operand, which is not normalised.
+// A lane's register e of a fragment feeds only the MFMAs of k element e, so the map runs one element ahead of the
+// matrix pipe: while the 4*FM MFMAs of element e execute (32 cycles each), the VALU maps element e+1 (seven
+// instructions per value, two of them transcendental); only the first element of a k-tile is mapped with the pipe idle.
+// The map of one value as seven single-instruction stages, so that the caller can place them between MFMAs.
+struct GnVal {
+    float v, u;
+};
+template <bool SILU>
+__device__ __forceinline__ void gn_op(int stage, GnVal& x, float a, float s, float t, bool live) {
+    switch (stage) {
+        case 0: x.v = fmaf(a, s, t); break;
+        case 1: if (SILU) x.u = -1.4426950408889634f * x.v; break;
+        case 2: if (SILU) x.u = __builtin_amdgcn_exp2f(x.u); break;
+        case 3: if (SILU) x.u = 1.0f + x.u; break;
+        case 4: if (SILU) x.u = __builtin_amdgcn_rcpf(x.u); break;
+        case 5: if (SILU) x.v = x.v * x.u; break;
+        default: x.v = live ? x.v : 0.f; break;
+    }
+}
+template <int FM, bool SILU>
+__device__ __forceinline__ void mma_tile_gn(f32x4 (&acc)[FM][4], const char* sa, const char* sw, int arow0, int wrow0,
+                                            int fr, int fq, const f32x4 (&s4)[2], const f32x4 (&t4)[2],
+                                            const uint32_t (&vmask)[FM], int bit, bool raw) {
+    // LDS returns in order: the first k-step's A fragments are requested first, so the first element's map starts
+    // while the other fragments are still on their way (the scale / shift chunks were requested before the k-tile's
+    // barrier by the caller)
+    u32x4 af[2][FM], wf[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[ks][i] = *reinterpret_cast<const u32x4*>(sa + swz(arow0 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[ks][j] = *reinterpret_cast<const u32x4*>(sw + swz(wrow0 + j * 16 + fr, ks * 4 + fq));
+        if (ks == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (raw) {
+        mfma_tile_frags<float, FM>(acc, af, wf);
+        return;
+    }
+    bool live[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) live[i] = (vmask[i] >> bit) & 1u;
+    GnVal cur[FM], nxt[FM];
+#pragma unroll
+    for (int st = 0; st < 7; ++st)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) gn_op<SILU>(st, cur[i], __uint_as_float(af[0][i][0]), s4[0][0], t4[0][0], live[i]);
+#pragma unroll
+    for (int step = 0; step < 8; ++step) {
+        const int ks = step >> 2, e = step & 3;
+        const int ks1 = ((step + 1) >> 2) & 1, e1 = (step + 1) & 3;
+        __builtin_amdgcn_sched_barrier(0);
+        // the order below is the order of issue: one MFMA, two instructions of the next element's map, ...
+#pragma unroll
+        for (int q = 0; q < 4 * FM; ++q) {
+            const int i = q >> 2, j = q & 3;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[ks][j][e]), cur[i].v, acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int op = 2 * q + r;  // stage-major over the FM values, so that neighbouring instructions are independent
+                if (step < 7 && op < 7 * FM)
+                    gn_op<SILU>(op / FM, nxt[op % FM], __uint_as_float(af[ks1][op % FM][e1]), s4[ks1][e1], t4[ks1][e1],
+                                live[op % FM]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) cur[i] = nxt[i];
     }
 }
 
@@ -551,9 +707,10 @@ template <int LOADS, int MAXY> __device__ __forceinline__ void wait_young(int yo
 // ------------------------------------------------------------------------------------------------
 // direct-to-LDS main loop
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool CONV, bool EARLY = false>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool CONV, bool EARLY = false, bool GN = false>
 __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
     static_assert(!EARLY || STAGES == 2, "the early-refill loop runs on two LDS buffers");
+    static_assert(!GN || (sizeof(T) == 4 && !EARLY), "fragment-side GroupNorm exists for the fp32 ring loop only");
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int FM = BM / (16 * WAVES_M);
     static_assert(BN == 64 * WAVES_N, "each wave owns 64 output columns");
@@ -589,6 +746,8 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
     // its run segment by segment (at most one tile entered late and one left early).
     long u = 0, u_end = 1;
     int sk_g = 0;
+    [[maybe_unused]] float* gn_tab = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES);
+    [[maybe_unused]] int gn_b = -1;  // sample whose scale / shift table sits in LDS
     [[maybe_unused]] int tl_seg = -1;
     [[maybe_unused]] unsigned long long tl_cycles = 0;  // shader-clock count at the start of the k loop (diagnostic build)
 #ifdef DM_TIMELINE
@@ -627,6 +786,29 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
         ++tl_seg;
         DM_TL(tl_seg, 0);  // segment entered
 
+        // fragment-side GroupNorm: per fragment row of this lane, which taps read real data
+        [[maybe_unused]] uint32_t gn_vmask[FM];
+        if constexpr (GN) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * 16 * FM + i * 16 + fr;
+                uint32_t bits = 0;
+                if (m < p.M) {
+                    if (CONV) {
+                        const int pix = m % (p.Hout * p.Wout);
+                        const int y = pix / p.Wout, x = pix - y * p.Wout;
+#pragma unroll
+                        for (int t9 = 0; t9 < 9; ++t9) {
+                            const int iy = y + t9 / 3 - 1, ix = x + t9 % 3 - 1;
+                            if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) bits |= 1u << t9;
+                        }
+                    } else {
+                        bits = 1u;
+                    }
+                }
+                gn_vmask[i] = bits;
+            }
+        }
         ARows<A_IT> rows;
         init_rows<A_IT, NT / 8>(rows, p, m0, tid >> 3, BM);
         // Running source pointers, advanced after every k-tile.  A row (or, in a convolution, a tap of a
@@ -777,9 +959,41 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
             if (kt0 + s < kt1) issue(kt0 + s, s);
+        if constexpr (GN) {
+            // The sample's scale / shift table, behind the ring, built while the first k-tiles are in flight; rebuilt when
+            // a work-list segment enters another sample (all waves passed the barrier at the top of the segment, so
+            // nobody still reads the old one).
+            const int b = m0 / p.rows_per_batch;
+            if (b != gn_b) {
+                gn_build_table<NT>(p, b, gn_tab);
+                gn_b = b;
+            }
+        }
 
+        // channel offset and tap of the k-tile about to be CONSUMED (the issue side runs STAGES-1 tiles ahead)
+        [[maybe_unused]] int gn_tap = 0, gn_c0 = 0;
+        if constexpr (GN) {
+            if (CONV) {
+                gn_tap = min(kt0 * BK / p.Cin, 9);
+                gn_c0 = kt0 * BK - gn_tap * p.Cin;
+            } else {
+                gn_c0 = kt0 * BK;
+            }
+        }
         int stage = 0;
         for (int kt = kt0; kt < kt1; ++kt) {
+            // fragment-side GroupNorm: this lane's scale / shift chunks of the k-tile, requested ahead of the wait
+            [[maybe_unused]] f32x4 gn_s4[2], gn_t4[2];
+            [[maybe_unused]] bool gn_raw = false;
+            if constexpr (GN) {
+                gn_raw = CONV ? gn_tap >= 9 : kt >= kt_second;
+                const float* ts = gn_tab + (gn_raw ? 0 : gn_c0);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    gn_s4[ks] = *reinterpret_cast<const f32x4*>(ts + (ks * 4 + fq) * 4);
+                    gn_t4[ks] = *reinterpret_cast<const f32x4*>(ts + p.gn_c + (ks * 4 + fq) * 4);
+                }
+            }
             // tile kt has landed once only the younger tiles in flight (at most STAGES-2, fewer at the end
             // of the run) are outstanding; the barrier makes every wave's share visible and retires all
             // reads of the stage refilled below
@@ -795,7 +1009,17 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
             if (nstage >= STAGES) nstage -= STAGES;
             if (DM_TL_ON(1) && kt + STAGES - 1 < kt1) issue(kt + STAGES - 1, nstage);
             const char* sa = smem + stage * STAGE_BYTES;
-            mma_tile<T, FM>(acc, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq);
+            if constexpr (GN) {
+                mma_tile_gn<FM, CONV>(acc, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq, gn_s4, gn_t4, gn_vmask,
+                                      CONV ? gn_tap : 0, gn_raw);
+                gn_c0 += BK;
+                if (CONV && gn_c0 == p.Cin && gn_tap < 9) {
+                    gn_c0 = 0;
+                    ++gn_tap;
+                }
+            } else {
+                mma_tile<T, FM>(acc, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq);
+            }
             if (++stage == STAGES) stage = 0;
         }
         }
@@ -910,6 +1134,24 @@ template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_M* WAVES_N, STAGES)) void conv3x3_igemm_kernel(
     GemmArgs p) {
     gemm_dma_body<T, BM, BN, WAVES_M, WAVES_N, STAGES, true, EARLY>(p);
+}
+
+// fp32 with the GroupNorm of the A operand applied to the fragments (conv: + SiLU; dense: affine only)
+// The table behind the ring lowers the blocks a CU holds, and the map keeps a k-tile's fragments and the scale / shift
+// chunks live: half the waves per SIMD of the plain kernel, i.e. twice its register budget.
+constexpr int gn_min_waves(int bm, int bn, int waves, int stages) {
+    const int w = dma_min_waves(bm, bn, waves, stages) / 2;
+    return w < 1 ? 1 : w;
+}
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, gn_min_waves(BM, BN, WAVES_M* WAVES_N, STAGES)) void gemm_gn_kernel(
+    GemmArgs p) {
+    gemm_dma_body<float, BM, BN, WAVES_M, WAVES_N, STAGES, false, false, true>(p);
+}
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, gn_min_waves(BM, BN, WAVES_M* WAVES_N, STAGES)) void conv3x3_gn_kernel(
+    GemmArgs p) {
+    gemm_dma_body<float, BM, BN, WAVES_M, WAVES_N, STAGES, true, false, true>(p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1400,8 +1642,10 @@ struct TileInfo {
     int bm, bn, threads, lds;
 };
 
-template <typename K> int launch_kernel(K kfn, DmLdsAttr& attr_done, const TileInfo& t, const GemmArgs& a, hipStream_t stream) {
-    if (const int rc = dm_set_lds_attr(reinterpret_cast<const void*>(kfn), attr_done, t.lds)) return rc;
+// lds_attr: the dynamic-LDS ceiling registered for the kernel when launches of it differ in their LDS size
+template <typename K> int launch_kernel(K kfn, DmLdsAttr& attr_done, const TileInfo& t, const GemmArgs& a, hipStream_t stream,
+                                        int lds_attr = 0) {
+    if (const int rc = dm_set_lds_attr(reinterpret_cast<const void*>(kfn), attr_done, lds_attr ? lds_attr : t.lds)) return rc;
     const int ntm = (a.M + t.bm - 1) / t.bm, ntn = (a.N + t.bn - 1) / t.bn;
     dim3 grid(a.streamk ? a.streamk : ntm * ntn, a.splitk > 1 ? a.splitk : 1, 1);
     hipLaunchKernelGGL(kfn, grid, dim3(t.threads), t.lds, stream, a);
@@ -1420,6 +1664,35 @@ int launch_dma(const GemmArgs& a, hipStream_t s) {
     const TileInfo t{BM, BN, WM * WN * 64, ST * (BM + BN) * 128};
     if (a.conv) return launch_kernel(conv3x3_igemm_kernel<T, BM, BN, WM, WN, ST, EARLY>, done_conv, t, a, s);
     return launch_kernel(gemm_dma_kernel<T, BM, BN, WM, WN, ST, EARLY>, done, t, a, s);
+}
+
+// fp32 with the GroupNorm of A applied to the fragments: the scale / shift table sits in LDS behind the ring
+template <int BM, int BN, int WM, int WN, int ST> int launch_gn(const GemmArgs& a, hipStream_t s) {
+    static DmLdsAttr done, done_conv;
+    const int ring = ST * (BM + BN) * 128;
+    const TileInfo t{BM, BN, WM * WN * 64, ring + gn_fuse_lds_bytes(a.gn_c)};
+    const int ceiling = ring + gn_fuse_lds_bytes(GN_FUSE_MAX_C);
+    if (a.conv) return launch_kernel(conv3x3_gn_kernel<BM, BN, WM, WN, ST>, done_conv, t, a, s, ceiling);
+    return launch_kernel(gemm_gn_kernel<BM, BN, WM, WN, ST>, done, t, a, s, ceiling);
+}
+bool gn_tile(int cfg) {
+    switch (cfg) {
+        case DM_TILE_D128x128_S2: case DM_TILE_D64x128_S3: case DM_TILE_D64x64_S4: case DM_TILE_D32x64_S4:
+        case DM_TILE_D128x64_S2: case DM_TILE_D64x64_S2:
+            return true;
+        default: return false;
+    }
+}
+int launch_gn_typed(const GemmArgs& a, int cfg, hipStream_t s) {
+    switch (cfg) {
+        case DM_TILE_D128x128_S2: return launch_gn<128, 128, 2, 2, 2>(a, s);
+        case DM_TILE_D64x128_S3: return launch_gn<64, 128, 2, 2, 3>(a, s);
+        case DM_TILE_D64x64_S4: return launch_gn<64, 64, 4, 1, 4>(a, s);
+        case DM_TILE_D32x64_S4: return launch_gn<32, 64, 2, 1, 4>(a, s);
+        case DM_TILE_D128x64_S2: return launch_gn<128, 64, 4, 1, 2>(a, s);
+        case DM_TILE_D64x64_S2: return launch_gn<64, 64, 4, 1, 2>(a, s);
+        default: return DM_ERR_ARG;
+    }
 }
 
 // 256 x 256 ping-pong tile: bf16 only (exact-fp32 MFMA is 16x slower per operand byte: operand traffic is not its limit)
@@ -1639,6 +1912,14 @@ extern "C" int dm_gemm_stats_supported(int tile, int rows_per_batch, int splitk)
     return rows_per_batch % tile_wave_rows(tile) == 0;
 }
 
+extern "C" int dm_gemm_gn_supported(int dtype, int tile, int conv, int c, int groups, int rows_per_batch, int splitk) {
+    int bm, bn;
+    (void)conv;
+    if (dtype != DM_F32 || !gn_tile(tile) || tile_dims(tile, &bm, &bn) || splitk > 1) return 0;
+    if (c <= 0 || c > GN_FUSE_MAX_C || c % 32 || groups <= 0 || groups > 64 || c % groups) return 0;
+    return rows_per_batch > 0 && rows_per_batch % bm == 0;
+}
+
 extern "C" long dm_gemm_streamk_workspace_bytes(int tile, int M, int N, int blocks) {
     int bm, bn;
     if (tile_dims(tile, &bm, &bn) || blocks <= 0) return -1;
@@ -1709,6 +1990,19 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     // fused statistics: a wave's rows must lie inside one sample, and the separate split-K reduction
     // launch does not produce them
     if (d->stats && (d->rows_per_batch % tile_wave_rows(tile) || d->m % d->rows_per_batch || splitk > 1)) return DM_ERR_ARG;
+    int gn_c = 0;
+    if (d->gn_sums) {
+        // GroupNorm of A inside the launch: every tile lies in one sample, whole k-tiles of normalised channels
+        gn_c = d->conv ? d->cin : (d->a2 ? d->k - d->cin2 : d->k);
+        if (!dm_gemm_gn_supported(d->dtype, tile, d->conv, gn_c, d->gn_groups, d->rows_per_batch, splitk)) return DM_ERR_ARG;
+        if (!d->gn_gamma || !d->gn_beta || (reinterpret_cast<uintptr_t>(d->gn_sums) & 7u) || d->ld_gn < gn_c ||
+            d->m % d->rows_per_batch || d->ln_in)
+            return DM_ERR_ARG;
+        if (d->conv ? (d->stride != 1 || d->up || d->pad_hi_only || d->hin != d->hout || d->win != d->wout || !d->gn_silu ||
+                       d->rows_per_batch != d->hout * d->wout)
+                    : (d->gn_silu || d->kpad != d->k))
+            return DM_ERR_ARG;
+    }
     int streamk = 0;
     if (splitk < 0) {
         // work-list form: -splitk blocks share the (tile, k-tile) list; never more blocks than list entries
@@ -1756,8 +2050,16 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     a.counters = static_cast<int*>(d->workspace);
     a.slabs = streamk ? reinterpret_cast<float*>(static_cast<char*>(d->workspace) + streamk_counter_bytes(tile, d->m, d->n))
                       : nullptr;
+    a.gn_sums = d->gn_sums;
+    a.ld_gn = d->ld_gn;
+    a.gn_gamma = d->gn_gamma;
+    a.gn_beta = d->gn_beta;
+    a.gn_eps = d->gn_eps;
+    a.gn_groups = d->gn_groups;
+    a.gn_c = gn_c;
 
-    int rc = d->dtype == DM_F32 ? launch_typed<float>(a, tile, stream) : launch_typed<bf16_t>(a, tile, stream);
+    int rc = d->gn_sums ? launch_gn_typed(a, tile, stream)
+                        : (d->dtype == DM_F32 ? launch_typed<float>(a, tile, stream) : launch_typed<bf16_t>(a, tile, stream));
     if (rc != DM_OK) return rc;
     if (splitk > 1) {
         const long total = (long)a.M * (a.N >> 2);

@@ -134,6 +134,13 @@ class Engine:
         self.fuse_skip = os.environ.get("DM_FUSE_SKIP", "1") != "0"  # residual_layer folded into the second conv
         self.fuse_tail = os.environ.get("DM_FUSE_TAIL", "1") != "0"  # linear_geglu_2 + residue + conv_output as one GEMM
         self.fuse_gn_stats = os.environ.get("DM_FUSE_GN_STATS", "1") == "1"
+        # fp32: GroupNorm (+ SiLU) applied to the A fragments of the convolution / projection that reads it
+        self.fuse_gn_apply = os.environ.get("DM_FUSE_GN_APPLY", "1") != "0"
+        # ... for convolutions only up to this many output channels.  The map is redone by every block that reads the
+        # element (9 taps x N/64 column tiles); with SiLU it holds two transcendental instructions, and the 320-channel
+        # 64 x 64 convolution measured 93 us as GroupNorm kernel + convolution against 114 us with the map inside.  The
+        # projections behind an AttentionBlock's GroupNorm (no SiLU, no taps) gain 1.1-1.2x and are always taken.
+        self.fuse_gn_conv_max_n = int(os.environ.get("DM_FUSE_GN_CONV_MAX_N", "64"))
         self.profile: Optional[dict] = None  # kernel class -> [events...] when profiling
         self._order_cache: Dict[Tuple[int, int, bool], torch.Tensor] = {}
         self.tile_override: Optional[Tuple[int, int]] = None
@@ -338,13 +345,29 @@ class Engine:
              rowbias: Optional[torch.Tensor] = None, rows_per_batch: int = 0, residual: Optional[torch.Tensor] = None,
              conv: Optional[dict] = None, nchw_out: Optional[torch.Tensor] = None, persistent=False,
              gn_batch: int = 0, act: Optional[str] = None, ln_in: Optional[torch.Tensor] = None,
-             ln_out: bool = False, a2: Optional[torch.Tensor] = None) -> torch.Tensor:
+             ln_out: bool = False, a2: Optional[torch.Tensor] = None, gn_in: Optional[dict] = None) -> torch.Tensor:
         """``gn_batch`` > 0: a GroupNorm over ``gn_batch`` samples reads the output next; its statistics are
         accumulated by this launch where the chosen tile allows it.
+        ``gn_in`` = dict(batch, hw, gamma, beta, eps, silu[, groups]): ``a`` is the INPUT of a GroupNorm (+ SiLU) whose
+        output is this launch's operand.  In fp32 mode, when the producer of ``a`` accumulated its statistics and the
+        tile allows it, the normalisation is applied to the A fragments inside the launch and the normalised tensor
+        is never written; otherwise the GroupNorm kernel runs first.
         ``ln_out``: a LayerNorm folded into a later GEMM reads the output next; per-row sums are accumulated
         here (fetch them with ``ln_stats(out)``).  ``ln_in``: such sums for the rows of ``a``; ``pw`` must have
         been packed with that LayerNorm (``pack_linear(..., ln=...)``)."""
         d = GemmDesc()
+        gn_rec = None
+        if gn_in is not None:
+            c_gn = a.shape[1]
+            geom_ok = conv is None or (conv.get("stride", 1) == 1 and not conv.get("up", 0)
+                                       and not conv.get("pad_hi_only", 0) and conv["hin"] == conv["hout"]
+                                       and conv["win"] == conv["wout"] and conv["hout"] * conv["wout"] == gn_in["hw"])
+            if (self.fuse_gn_apply and self.dtype == torch.float32 and geom_ok and ln_in is None and a2 is None
+                    and (conv is None or pw.n <= self.fuse_gn_conv_max_n)
+                    and (conv is not None) == bool(gn_in["silu"]) and c_gn % 32 == 0 and c_gn <= 1280):
+                gn_rec = self._gn_lookup(a, gn_in["batch"])
+            if gn_rec is None:
+                a = self._gn_unfused(a, gn_in)
         if conv is not None:
             m = conv["batch"] * conv["hout"] * conv["wout"]
             d.conv, d.hin, d.win, d.hout, d.wout = 1, conv["hin"], conv["win"], conv["hout"], conv["wout"]
@@ -403,6 +426,13 @@ class Engine:
             # operand) are part of the key: a tile chosen for one use is never silently applied to another
             key = (m, pw.n, pw.k, d.conv, d.stride, d.up, d.epi, residual is not None, rowbias is not None, no_legacy,
                    gn_batch > 0 and self.fuse_gn_stats, bool(d.a2), d.pad_hi_only)
+            if gn_rec is not None:
+                # the fragment-side GroupNorm changes the LDS footprint and the loop: its own entry
+                key = key + ("gn_in",)
+                d.gn_sums, d.ld_gn = gn_rec["stats_ptr"], gn_rec["ld"]
+                d.gn_gamma, d.gn_beta = gn_in["gamma"].data_ptr(), gn_in["beta"].data_ptr()
+                d.gn_eps, d.gn_silu, d.gn_groups = gn_in["eps"], int(gn_in["silu"]), gn_in.get("groups", 32)
+                d.rows_per_batch = gn_in["hw"]
             best = self.tuned.get(key)
             if best is None and self.autotune and not self.arena.frozen and self.profile is None:
                 best = self._tune(d, key, legacy=not no_legacy)
@@ -413,6 +443,21 @@ class Engine:
         if (ln_in is not None or ln_out) and sk.value > 1:
             sk.value = 1  # the separate split-K reduction launch does not carry the LayerNorm epilogue
         d.tile, d.splitk = tile.value, sk.value
+        if gn_rec is not None:
+            if self.tile_override is not None:
+                d.gn_sums, d.ld_gn = gn_rec["stats_ptr"], gn_rec["ld"]
+                d.gn_gamma, d.gn_beta = gn_in["gamma"].data_ptr(), gn_in["beta"].data_ptr()
+                d.gn_eps, d.gn_silu, d.gn_groups = gn_in["eps"], int(gn_in["silu"]), gn_in.get("groups", 32)
+                d.rows_per_batch = gn_in["hw"]
+            if not self.lib.dm_gemm_gn_supported(self.dm, tile.value, d.conv, a.shape[1], d.gn_groups, gn_in["hw"], sk.value):
+                # the chosen tile has no fragment-side form for this shape: normalise with the stand-alone kernel
+                a = self._gn_unfused(a, gn_in)
+                d.a, d.lda = a.data_ptr(), a.stride(0)
+                d.gn_sums = None
+                d.rows_per_batch = rows_per_batch
+                gn_rec = None
+            else:
+                self._gn_auto.pop(a.data_ptr(), None)
         if ln_in is not None:
             if pw.colsum is None:
                 raise RuntimeError("ln_in needs weights packed with their LayerNorm")
@@ -445,6 +490,10 @@ class Engine:
                         + (f" s={d.stride} up={d.up}" if conv is not None else "")):
             check(self.lib.dm_gemm(C.byref(d), self.stream), klass)
         return out
+
+    def _gn_unfused(self, a: torch.Tensor, gn_in: dict) -> torch.Tensor:
+        return self.groupnorm(a, gn_in["batch"], gn_in["hw"], gn_in["gamma"], gn_in["beta"], gn_in["eps"],
+                              silu=bool(gn_in["silu"]), groups=gn_in.get("groups", 32))
 
     def _bind_workspace(self, d: GemmDesc, m: int, n: int, sk: int):
         need = self.lib.dm_gemm_workspace_bytes(m, n, sk)

@@ -170,15 +170,17 @@ def run_residual_block(eng: Engine, pk: NS, x, batch: int, h: int, w: int, tproj
         out = eng.new(batch * hw, pk.cout)
     mark = eng.arena.mark()
     geom = dict(batch=batch, hin=h, win=w, hout=h, wout=w)
-    a = eng.groupnorm(x, batch, hw, pk.gn1_w, pk.gn1_b, pk.gn1_eps, silu=True)
-    a = eng.gemm(a, pk.conv1, rowbias=tproj, rows_per_batch=hw, conv=dict(geom, cin_real=pk.cin), gn_batch=batch)
-    a = eng.groupnorm(a, batch, hw, pk.gn2_w, pk.gn2_b, pk.gn2_eps, silu=True)
+    # Both GroupNorm + SiLU pairs go to the convolution behind them as `gn_in`: in fp32 mode the convolution
+    # normalises its A fragments itself (no launch, no normalised tensor), otherwise the GroupNorm kernel runs first.
+    gn1 = dict(batch=batch, hw=hw, gamma=pk.gn1_w, beta=pk.gn1_b, eps=pk.gn1_eps, silu=True)
+    gn2 = dict(batch=batch, hw=hw, gamma=pk.gn2_w, beta=pk.gn2_b, eps=pk.gn2_eps, silu=True)
+    a = eng.gemm(x, pk.conv1, rowbias=tproj, rows_per_batch=hw, conv=dict(geom, cin_real=pk.cin), gn_batch=batch, gn_in=gn1)
     # the block output is group-normalised by whatever follows (ResidualBlock, AttentionBlock or FinalLayer)
     if pk.fold_skip:
-        eng.gemm(a, pk.conv2, out=out, conv=dict(geom, cin_real=pk.cout, skip=x), gn_batch=batch)
+        eng.gemm(a, pk.conv2, out=out, conv=dict(geom, cin_real=pk.cout, skip=x), gn_batch=batch, gn_in=gn2)
     else:
         skip = x if pk.res is None else eng.gemm(x, pk.res)
-        eng.gemm(a, pk.conv2, out=out, residual=skip, conv=dict(geom, cin_real=pk.cout), gn_batch=batch)
+        eng.gemm(a, pk.conv2, out=out, residual=skip, conv=dict(geom, cin_real=pk.cout), gn_batch=batch, gn_in=gn2)
     eng.arena.release(mark)
     return out
 
@@ -215,16 +217,16 @@ def run_attention_block(eng: Engine, pk: NS, x, batch: int, h: int, w: int, kv, 
     if out is None:
         out = eng.new(batch * s, pk.c)
     mark = eng.arena.mark()
-    a = eng.groupnorm(x, batch, s, pk.gn_w, pk.gn_b, pk.gn_eps, silu=False)
+    gn = dict(batch=batch, hw=s, gamma=pk.gn_w, beta=pk.gn_b, eps=pk.gn_eps, silu=False)
     if pk.fold:
         # The three LayerNorms never run as kernels: each GEMM that writes the residual stream also accumulates
         # the row sums, and the GEMM behind the LayerNorm (weights pre-scaled by gamma) applies mean / rstd.
-        t = eng.gemm(a, pk.conv_in, ln_out=True)
+        t = eng.gemm(x, pk.conv_in, ln_out=True, gn_in=gn)
         t = run_self_attention(eng, pk.sa, t, batch, s, residual=t, ln_in=eng.ln_stats(t), ln_out=True)
         t = run_cross_attention(eng, pk.ca, t, kv, batch, s, sk, residual=t, ln_in=eng.ln_stats(t), ln_out=True)
         a = eng.gemm(t, pk.geglu1, ln_in=eng.ln_stats(t))
     else:
-        t = eng.gemm(a, pk.conv_in)
+        t = eng.gemm(x, pk.conv_in, gn_in=gn)
         a = eng.layernorm(t, pk.ln1_w, pk.ln1_b, pk.ln1_eps)
         t = run_self_attention(eng, pk.sa, a, batch, s, residual=t)
         a = eng.layernorm(t, pk.ln2_w, pk.ln2_b, pk.ln2_eps)
@@ -362,9 +364,9 @@ def diffusion_forward_into(eng: Engine, pk: NS, latent_f32: torch.Tensor, time_f
         tproj = time_projections(eng, pk, time_f32)
     x = eng.nchw_to_rows(latent_f32, cpad=_rup(cin, 8))
     x, ho, wo = run_unet(eng, pk.unet, x, batch, h, w, tproj, kvs, sk)
-    a = eng.groupnorm(x, batch, hw, pk.final.gn_w, pk.final.gn_b, pk.final.gn_eps, silu=True)
-    eng.gemm(a, pk.final.conv, nchw_out=eps_out, rows_per_batch=hw,
-             conv=dict(batch=batch, hin=h, win=w, hout=h, wout=w, cin_real=pk.final.cin))
+    eng.gemm(x, pk.final.conv, nchw_out=eps_out, rows_per_batch=hw,
+             conv=dict(batch=batch, hin=h, win=w, hout=h, wout=w, cin_real=pk.final.cin),
+             gn_in=dict(batch=batch, hw=hw, gamma=pk.final.gn_w, beta=pk.final.gn_b, eps=pk.final.gn_eps, silu=True))
     return eps_out
 
 

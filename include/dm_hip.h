@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 7
+#define DM_ABI_VERSION 8
 
 #define DM_F32 0
 #define DM_BF16 1
@@ -136,6 +136,22 @@ typedef struct DmGemmDesc {
      * above / left, i.e. F.pad(x, (0, 1, 0, 1)) followed by a padding-0 convolution - the stride-2 convolutions of
      * the VAE encoder (src/models/encoder.py:179-185).  Not with `up`, not with `a2`. */
     int pad_hi_only;
+    /* GroupNorm (+ SiLU) of the A operand applied inside this launch (NULL = none; fp32 only): the tensor `a` is the
+     * INPUT of nn.GroupNorm(gn_groups, C) (blocks.py:58-59,68-69,128; diffusion.py:44-45) and the product is taken
+     * over silu(groupnorm(a)) (conv) / groupnorm(a) (dense) without that tensor ever being written.  gn_sums are the
+     * per-channel fp64 (sum, sumsq) of `a`, [batch][2][ld_gn], as accumulated through `stats` by the launch that wrote
+     * it.  Every block folds them to per-channel scale / shift in LDS and applies them to its A fragments in
+     * registers; padding taps stay zero, the appended operand `a2` is not normalised.  Needs a direct-to-LDS tile
+     * (DM_TILE_D*), C = cin (conv) or k - cin2 (dense) a multiple of 32 and of gn_groups and at most 1280,
+     * rows_per_batch a multiple of the tile's rows, stride 1 / same size / no upsampling, gn_silu = 1 for conv and
+     * 0 for dense; dm_gemm_gn_supported() tells. */
+    const double* gn_sums;
+    long ld_gn;
+    const float* gn_gamma;
+    const float* gn_beta;
+    float gn_eps;
+    int gn_silu;
+    int gn_groups;
 } DmGemmDesc;
 
 int dm_gemm(const DmGemmDesc* d, hipStream_t stream);
@@ -147,6 +163,8 @@ long dm_gemm_workspace_bytes(int m, int n, int splitk);
  * workspace. */
 long dm_gemm_streamk_workspace_bytes(int tile, int m, int n, int blocks);
 int dm_gemm_stats_supported(int tile, int rows_per_batch, int splitk);
+/* 1 when DmGemmDesc.gn_sums may be used with this tile: C = channels that are normalised (see above). */
+int dm_gemm_gn_supported(int dtype, int tile, int conv, int c, int groups, int rows_per_batch, int splitk);
 /* order[p] = source weight row of packed row p (or -1 for a zero row), for p in [0, npad). */
 int dm_pack_weight_order(int n, int npad, int geglu, int* order_host);
 /* Device-side packing of an ACTIVATION matrix into the `w` operand layout, so that a product of two activation

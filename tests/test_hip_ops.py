@@ -185,6 +185,73 @@ def test_gemm_fused_groupnorm_statistics(eng, tile, sk):
     assert max_rel(out.float(), ref) < (2e-5 if eng.dtype == torch.float32 else 2e-2)
 
 
+GN_TILES = (_lib.TILE_D128x128_S2, _lib.TILE_D64x128_S3, _lib.TILE_D64x64_S4, _lib.TILE_D32x64_S4, _lib.TILE_D128x64_S2,
+            _lib.TILE_D64x64_S2)
+
+
+@pytest.mark.parametrize("tile", GN_TILES)
+@pytest.mark.parametrize("sk", [1, -7, -60])
+@pytest.mark.parametrize("kind", ["conv", "conv+pointwise", "dense"])
+def test_gemm_groupnorm_on_a_fragments(dev, tile, sk, kind):
+    """fp32: GroupNorm (+ SiLU) of the operand applied inside the consuming launch (blocks.py:58-59,68-69,128) from the
+    statistics the producing launch accumulated; padding taps stay zero, the appended pointwise operand stays raw.
+    Three samples, so work-list segments cross sample boundaries and the scale / shift table is rebuilt."""
+    eng = Engine.get(dev, torch.float32)
+    eng.reset()
+    b, h, w, k0, c, n = 3, 16, 8, 64, 320, 192
+    hw, m = h * w, b * h * w
+    a0 = tin("gnf.a0", (m, k0)); w0 = tin("gnf.w0", (c, k0), scale=1 / math.sqrt(k0)); b0 = tin("gnf.b0", (c,)) + 0.3
+    gamma = tin("gnf.g", (c,)) + 1; beta = tin("gnf.be", (c,)) * 0.5
+    lin0 = torch.nn.Linear(k0, c)
+    with torch.no_grad():
+        lin0.weight.copy_(w0); lin0.bias.copy_(b0)
+    x = eng.gemm(up(eng, a0), eng.pack_linear(lin0), gn_batch=b)  # producer: writes x and its per-channel sums
+    assert eng._gn_lookup(x, b) is not None
+    x_ref = a0 @ w0.t() + b0
+    xn = F.group_norm(x_ref.reshape(b, hw, c).permute(0, 2, 1), 32, gamma, beta, eps=1e-5)  # (b, c, hw)
+    gn = dict(batch=b, hw=hw, gamma=gamma.to(dev), beta=beta.to(dev), eps=1e-5, silu=kind != "dense")
+    eng.tile_override = (tile, sk)
+
+    def no_fallback(*_):
+        raise AssertionError("the fragment-side form did not run (fell back to the GroupNorm kernel)")
+
+    eng._gn_unfused = no_fallback
+    max_n, eng.fuse_gn_conv_max_n = eng.fuse_gn_conv_max_n, 1 << 20  # the engine's default keeps wide convolutions unfused
+    try:
+        if kind == "dense":
+            w1 = tin("gnf.w1", (n, c), scale=1 / math.sqrt(c)); b1 = tin("gnf.b1", (n,))
+            lin = torch.nn.Linear(c, n)
+            with torch.no_grad():
+                lin.weight.copy_(w1); lin.bias.copy_(b1)
+            out = eng.gemm(x, eng.pack_linear(lin), gn_in=gn)
+            ref = xn.permute(0, 2, 1).reshape(m, c) @ w1.t() + b1
+        else:
+            conv = torch.nn.Conv2d(c, n, 3, padding=1)
+            w1 = tin("gnf.cw", (n, c, 3, 3), scale=1 / math.sqrt(9 * c)); b1 = tin("gnf.cb", (n,))
+            with torch.no_grad():
+                conv.weight.copy_(w1); conv.bias.copy_(b1)
+            img = F.silu(xn).reshape(b, c, h, w)
+            ref = F.conv2d(img, w1, b1, padding=1)
+            geom = dict(batch=b, hin=h, win=w, hout=h, wout=w, cin_real=c)
+            if kind == "conv+pointwise":
+                c2 = 64
+                skip = torch.nn.Conv2d(c2, n, 1)
+                ws = tin("gnf.sw", (n, c2, 1, 1), scale=1 / math.sqrt(c2)); bs = tin("gnf.sb", (n,))
+                with torch.no_grad():
+                    skip.weight.copy_(ws); skip.bias.copy_(bs)
+                s_in = tin("gnf.s", (m, c2))
+                ref = ref + F.conv2d(s_in.reshape(b, h, w, c2).permute(0, 3, 1, 2), ws, bs)
+                out = eng.gemm(x, eng.pack_conv3x3(conv, skip=skip), conv=dict(geom, skip=up(eng, s_in)), gn_in=gn)
+            else:
+                out = eng.gemm(x, eng.pack_conv3x3(conv), conv=geom, gn_in=gn)
+            ref = ref.permute(0, 2, 3, 1).reshape(m, n)
+    finally:
+        eng.tile_override = None
+        eng.fuse_gn_conv_max_n = max_n
+        del eng._gn_unfused
+    assert max_rel(out.float().cpu(), ref) < 2e-5
+
+
 @pytest.mark.parametrize("geglu", [False, True])
 @pytest.mark.parametrize("tile,sk", [(_lib.TILE_AUTO, 1), (_lib.TILE_D128x128_S2, -40), (_lib.TILE_D64x64_S2, 1),
                                      (_lib.TILE_D256x256_S2, 1), (_lib.TILE_D256x256_S2, -40)])
