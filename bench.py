@@ -263,7 +263,7 @@ def main():
             "config": {"workload": cfg["name"], "batch_per_gpu": B, "global_batch": global_batch,
                        "latent": f"{HW}x{HW}", "ddpm_steps": T, "hip_graph": sched.use_hip_graph,
                        "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_igemm_kernel" + (" + conv3x3_wide_kernel" if cfg["dtype"] == "bf16" else ""),
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_igemm_kernel" + (" + conv3x3_wide_kernel" if cfg["dtype"] == "bf16" else " + conv3x3_gn_kernel"),
                          "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(tflops / peak, 4), "traffic": pmc_traffic(args.config, B, HW),
                          "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, separate passes)",

@@ -94,6 +94,7 @@ _PROTOS = {
     "dm_ddim_step": (C.c_int, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp]),
     "dm_ksampler_input": (C.c_int, [_vp, _vp, _l, _i, _vp, _vp, _vp]),
     "dm_ksampler_step": (C.c_int, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _f, _i, _vp]),
+    "dm_klms_step": (C.c_int, [_vp, _vp, _vp, _l, _vp, _vp, _i, _i, _vp, _f, _i, _vp]),
     "dm_scale_add": (C.c_int, [_vp, _vp, _vp, _i, _l, _vp, _vp, _vp, _f, _vp]),
     "dm_axpbypcz": (C.c_int, [_vp, _f, _vp, _f, _vp, _f, _vp, _l, _vp]),
     "dm_nchw_to_rows": (C.c_int, [_vp, _i, _i, _i, _vp, _l, _i, _i, _vp]),

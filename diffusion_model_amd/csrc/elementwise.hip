@@ -118,6 +118,34 @@ __global__ __launch_bounds__(EW_THREADS) void ksampler_step_kernel(const float* 
     }
 }
 
+// Linear multistep update (src/sampling/k_lms.py:113-137) inside the captured loop.  The guided model output o_s goes
+// into slot s % ring of a history ring; out = c[s][0] o_s + c[s][1] o_(s-1) + ... over the order[s] newest outputs,
+// accumulated in the order of the launch-by-launch path (alpha * x, then 1 * result + c * o per older output).  As in
+// the reference, the incoming latents do not enter the result.
+__global__ __launch_bounds__(EW_THREADS) void klms_step_kernel(const float* __restrict__ eps, float* hist, float* __restrict__ out,
+                                                               long n, const float* __restrict__ coef,
+                                                               const int* __restrict__ order, int max_order, int ring,
+                                                               const int* __restrict__ step_index, float cfg_scale,
+                                                               int do_cfg) {
+    const int s = *step_index;
+    const int ord = order[s];
+    const float* c = coef + (long)s * max_order;
+    float* cur = hist + (long)(s % ring) * n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float o = eps[i];
+        if (do_cfg) {
+            const float un = eps[n + i];
+            const float diff = __fadd_rn(__fmul_rn(1.0f, o), __fmul_rn(-1.0f, un));
+            o = __fadd_rn(__fmul_rn(cfg_scale, diff), __fmul_rn(1.0f, un));
+        }
+        cur[i] = o;
+        float v = __fmul_rn(c[0], o);
+        for (int j = 1; j < ord; ++j)
+            v = __fadd_rn(__fmul_rn(1.0f, v), __fmul_rn(c[j], hist[(long)((s - j) % ring) * n + i]));
+        out[i] = v;
+    }
+}
+
 // ---- time path: y[b][n] = sum_k f(x[b][k]) w[n][k] + bias[n]; one wave per output column ----------
 constexpr int LR_BATCH = 8;
 __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
@@ -400,6 +428,16 @@ extern "C" int dm_ksampler_step(const float* x, const float* eps, const float* n
     if (!x || !eps || !out || !coef || !step_index || n <= 0) return DM_ERR_ARG;
     hipLaunchKernelGGL(ksampler_step_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, stream, x, eps, noise, out, n, coef,
                        step_index, cfg_scale, do_cfg);
+    return dm_check_launch();
+}
+
+extern "C" int dm_klms_step(const float* eps, float* history, float* out, long n, const float* coef, const int* order,
+                            int max_order, int ring, const int* step_index, float cfg_scale, int do_cfg,
+                            hipStream_t stream) {
+    if (!eps || !history || !out || !coef || !order || !step_index || n <= 0 || max_order < 1 || ring < max_order)
+        return DM_ERR_ARG;
+    hipLaunchKernelGGL(klms_step_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, stream, eps, history, out, n, coef, order,
+                       max_order, ring, step_index, cfg_scale, do_cfg);
     return dm_check_launch();
 }
 

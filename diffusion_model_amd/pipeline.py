@@ -50,14 +50,15 @@ def denoise(model, sampler: BaseSampler, context: torch.Tensor, latents: torch.T
             do_cfg: bool = True, use_hip_graph: bool = True) -> torch.Tensor:
     """Run ``sampler`` over its remaining timesteps; returns the final latents.
 
-    With this package's ``Diffusion`` and an Euler / Euler-ancestral sampler the loop body is captured once as a hipGraph
-    and replayed (per-step scalars and the pre-drawn ancestral noise live in device tables); results are bitwise those
-    of the step-by-step path below, which remains for other models and for ``KLMSSampler`` (whose update reads a
-    history of model outputs)."""
+    With this package's ``Diffusion`` and one of this package's samplers the loop body is captured once as a hipGraph
+    and replayed (per-step scalars, the pre-drawn ancestral noise and the multistep sampler's history of model outputs
+    live on the device); results are bitwise those of the step-by-step path below, which remains for other models,
+    other samplers and a ``KLMSSampler`` that already holds outputs of earlier steps."""
     from .models.diffusion import Diffusion
-    from .sampling import KEulerAncestralSampler, KEulerSampler
-    if (use_hip_graph and isinstance(model, Diffusion) and type(sampler) in (KEulerSampler, KEulerAncestralSampler)
-            and len(sampler.timesteps) > 0):
+    from .sampling import KEulerAncestralSampler, KEulerSampler, KLMSSampler
+    if (use_hip_graph and isinstance(model, Diffusion) and len(sampler.timesteps) > 0
+            and (type(sampler) in (KEulerSampler, KEulerAncestralSampler)
+                 or (type(sampler) is KLMSSampler and not sampler.outputs))):
         return _denoise_graph(model, sampler, context, latents, cfg_scale, do_cfg)
     batch = latents.shape[0]
     for timestep in sampler.timesteps:
@@ -76,17 +77,23 @@ def denoise(model, sampler: BaseSampler, context: torch.Tensor, latents: torch.T
 
 def _denoise_graph(model, sampler, context, latents, cfg_scale, do_cfg):
     import numpy as np
-    from .sampling import KEulerAncestralSampler
-    from .schedulers.ddpm_scheduler import KStepLoop
+    from .sampling import KEulerAncestralSampler, KLMSSampler
+    from .schedulers.ddpm_scheduler import KLMSLoop, KStepLoop
     require_hip(latents, "denoise")
     n = len(sampler.timesteps)
     first = sampler.step_count
     ancestral = isinstance(sampler, KEulerAncestralSampler)
-    scales, coefs = [], []
+    lms = isinstance(sampler, KLMSSampler)
+    scales, coefs, orders = [], [], []
     for t in range(first, first + n):
         s_from, s_to = sampler.sigmas[t], sampler.sigmas[t + 1]
         scales.append(sampler.get_input_scale(t))
-        if ancestral:  # the scalars KEulerAncestralSampler.step forms
+        if lms:  # the history starts empty (checked by the caller): step i of this loop sums min(i + 1, order) outputs
+            order = min(t - first + 1, sampler.lms_order)
+            c = sampler._coefficients(t, order)
+            coefs.append(c + [0.0] * (sampler.lms_order - order))
+            orders.append(order)
+        elif ancestral:  # the scalars KEulerAncestralSampler.step forms
             s_up = s_to * np.sqrt(1 - (s_to ** 2 / s_from ** 2))
             s_down = np.sqrt(s_to ** 2 - s_up ** 2)
             coefs.append([s_down - s_from, s_up])
@@ -96,17 +103,23 @@ def _denoise_graph(model, sampler, context, latents, cfg_scale, do_cfg):
     # the model never touches the sampler's generator: one draw per step, in step order, can be made up front
     noises = [draw_normal(shape, sampler.generator, latents.device) for _ in range(n)] if ancestral else []
     eng, _ = model.hip_pack(latents.device)
-    key = (id(model), id(eng), shape, str(latents.device), context.shape[1], type(sampler).__name__, first, n,
+    key = (id(model), id(eng), shape, str(latents.device), context.shape[1], type(sampler).__name__, getattr(sampler, "lms_order", 0), first, n,
            tuple(float(t) for t in sampler.timesteps), float(cfg_scale), bool(do_cfg))
     cache = sampler.__dict__.setdefault("_dm_loops", {})
     loop = cache.get(key)
     if loop is None:
         cache.clear()
-        loop = KStepLoop(model, shape, latents.device, context.shape[1], [int(t) for t in sampler.timesteps], scales, coefs,
-                         n_noise=len(noises), cfg_scale=cfg_scale, do_cfg=do_cfg)
+        if lms:
+            loop = KLMSLoop(model, shape, latents.device, context.shape[1], [int(t) for t in sampler.timesteps], scales,
+                            coefs, orders, sampler.lms_order, cfg_scale=cfg_scale, do_cfg=do_cfg)
+        else:
+            loop = KStepLoop(model, shape, latents.device, context.shape[1], [int(t) for t in sampler.timesteps], scales,
+                             coefs, n_noise=len(noises), cfg_scale=cfg_scale, do_cfg=do_cfg)
         cache[key] = loop
     out = loop.run(_GraphSwitch, model, latents, noises, context, None)
     sampler.step_count += n
+    if lms:
+        sampler.outputs = loop.newest_outputs(n)
     return out.to(latents.dtype)
 
 

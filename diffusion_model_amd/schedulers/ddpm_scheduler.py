@@ -316,3 +316,24 @@ class KStepLoop(StepLoop):
                                         self.noise.data_ptr() if self.n_noise else None, self.x.data_ptr(), self.x.numel(),
                                         self.kcoef.data_ptr(), self.counter.data_ptr(), self.cfg_scale, self.do_cfg, s),
               "ksampler_step")
+
+
+class KLMSLoop(KStepLoop):
+    """The same captured loop for ``KLMSSampler``: the update is the linear multistep sum over a ring of the newest
+    model outputs kept on the device (``dm_klms_step``); per-step coefficients and orders are device tables."""
+
+    def __init__(self, model, shape, device, sk, timesteps, scales, coefs, orders, max_order: int, cfg_scale: float,
+                 do_cfg: bool):
+        super().__init__(model, shape, device, sk, timesteps, scales, coefs, n_noise=0, cfg_scale=cfg_scale, do_cfg=do_cfg)
+        self.max_order = int(max_order)
+        self.orders = torch.tensor(orders, dtype=torch.int32, device=device)
+        self.history = torch.zeros((self.max_order,) + tuple(shape), dtype=torch.float32, device=device)
+
+    def _update(self, s):
+        check(self.lib.dm_klms_step(self.model_out.data_ptr(), self.history.data_ptr(), self.x.data_ptr(), self.x.numel(),
+                                    self.kcoef.data_ptr(), self.orders.data_ptr(), self.max_order, self.max_order,
+                                    self.counter.data_ptr(), self.cfg_scale, self.do_cfg, s), "klms_step")
+
+    def newest_outputs(self, steps: int):
+        """The model outputs a step-by-step ``KLMSSampler`` would hold after ``steps`` steps, newest first."""
+        return [self.history[(steps - 1 - j) % self.max_order].clone() for j in range(min(steps, self.max_order))]

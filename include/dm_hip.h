@@ -263,6 +263,13 @@ int dm_ksampler_input(const float* x, float* out, long n, int copies, const floa
                       hipStream_t stream);
 int dm_ksampler_step(const float* x, const float* eps, const float* noise, float* out, long n, const float* coef,
                      const int* step_index, float cfg_scale, int do_cfg, hipStream_t stream);
+/* KLMSSampler.step (src/sampling/k_lms.py:113-137) for the captured loop: the (guided, as in dm_ksampler_step) model
+ * output of step s = *step_index is stored into history[(s % ring) * n ...] and
+ * out = coef[s][0] * o_s + coef[s][1] * o_(s-1) + ... over the order[s] newest outputs (coef: [steps][max_order] fp32,
+ * order: [steps] int32, ring >= max_order history slots of n floats).  The incoming latents do not enter the result,
+ * as in the reference. */
+int dm_klms_step(const float* eps, float* history, float* out, long n, const float* coef, const int* order,
+                 int max_order, int ring, const int* step_index, float cfg_scale, int do_cfg, hipStream_t stream);
 
 /* out[(b, s)][:] = table[tokens[b][s]][:] + pos[s][:] in the engine dtype.  Replaces CLIPEmbedding.forward
  * (src/models/clip.py:52-57): nn.Embedding lookup + learned positional add.  tokens: int64 [rows],

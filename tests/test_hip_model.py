@@ -419,23 +419,23 @@ def test_cfg_denoise_loop_matches_oracle(model_f32, dev):
 
 
 def test_ksampler_graph_loop_is_bitwise_the_stepwise_loop(model_f32, dev):
-    """pipeline.denoise as a captured step graph (Euler and Euler-ancestral, with and without guidance, an img2img
-    start in the middle of the schedule) against the same loop run launch by launch: identical bits, and the
-    sampler's step counter / generator end up in the same state."""
+    """pipeline.denoise as a captured step graph (Euler, Euler-ancestral and the linear multistep sampler, with and
+    without guidance, an img2img start in the middle of the schedule) against the same loop run launch by launch:
+    identical bits, and the sampler's step counter / generator / history of model outputs end up in the same state."""
     from diffusion_model_amd import pipeline
-    from diffusion_model_amd.sampling import KEulerAncestralSampler, KEulerSampler
+    from diffusion_model_amd.sampling import KEulerAncestralSampler, KEulerSampler, KLMSSampler
     gen = torch.Generator().manual_seed(21)
     ctx2 = torch.randn(2, 77, 768, generator=gen).to(dev)
     lat = torch.randn(1, 4, 16, 16, generator=gen).to(dev)
-    cases = [(KEulerSampler, True, None), (KEulerSampler, False, None), (KEulerAncestralSampler, True, None),
-             (KEulerAncestralSampler, True, 0.5)]
-    for cls, cfg, strength in cases:
-        outs, counts, states = [], [], []
+    cases = [(KEulerSampler, True, None, 4), (KEulerSampler, False, None, 4), (KEulerAncestralSampler, True, None, 4),
+             (KEulerAncestralSampler, True, 0.5, 4), (KLMSSampler, True, None, 6), (KLMSSampler, False, 0.5, 12)]
+    for cls, cfg, strength, steps in cases:
+        outs, counts, states, hist = [], [], [], []
         # capture + replay first (its eager step settles the tile choice of every shape, which fixes the fp32
         # summation order), then a replay of the kept graph, then launch by launch on the same tiles
         for graph in (True, True, False):
             kw = dict(generator=torch.Generator().manual_seed(3)) if cls is KEulerAncestralSampler else {}
-            smp = cls(n_inference_steps=4, **kw)
+            smp = cls(n_inference_steps=steps, **kw)
             x = lat * float(smp.initial_scale)
             if strength is not None:
                 x = pipeline.img2img_latents(smp, lat, strength, torch.Generator().manual_seed(4))
@@ -447,8 +447,10 @@ def test_ksampler_graph_loop_is_bitwise_the_stepwise_loop(model_f32, dev):
             outs.append(out)
             counts.append(smp.step_count)
             states.append(smp.generator.get_state() if smp.generator is not None else None)
+            hist.append(list(getattr(smp, "outputs", [])))
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (cls.__name__, cfg, strength)
-        assert counts[0] == counts[1] == counts[2] == 4
+        assert counts[0] == counts[1] == counts[2] == steps
+        assert len(hist[0]) == len(hist[2]) and all(torch.equal(a, b) for a, b in zip(hist[0], hist[2]))
         if states[0] is not None:
             assert torch.equal(states[0], states[1])
 
