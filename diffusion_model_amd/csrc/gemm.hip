@@ -298,9 +298,20 @@ __device__ __forceinline__ void gn_build_table(const GemmArgs& p, int b, float* 
     for (int item = tid; item < groups * 8; item += NT) {
         const int grp = item >> 3, part = item & 7;
         double a = 0.0, d = 0.0;
-        for (int ch = grp * cpg + part; ch < (grp + 1) * cpg; ch += 8) {
-            a += src[ch];
-            d += src[p.ld_gn + ch];
+        const int c1 = (grp + 1) * cpg;
+        for (int ch = grp * cpg + part; ch < c1; ch += 8 * 5) {  // five requests in flight, see gn_apply_kernel
+            double va[5], vd[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int cc = ch + 8 * u;
+                va[u] = cc < c1 ? src[cc] : 0.0;
+                vd[u] = cc < c1 ? src[p.ld_gn + cc] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                a += va[u];
+                d += vd[u];
+            }
         }
         sub[item * 2] = a;
         sub[item * 2 + 1] = d;

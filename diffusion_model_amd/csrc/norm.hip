@@ -151,11 +151,25 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
         const int grp = item >> 3, part = item & 7;
         double a = 0.0, d = 0.0;
         if (sums) {
-            // per-channel sums accumulated by the kernel that wrote x
+            // per-channel sums accumulated by the kernel that wrote x.  Five strided channels are requested before the
+            // first is added (a loop of load - wait - add pays one memory latency per channel: five in a row at 1280
+            // channels, and this fold is the serial head of every block); lanes past the group add zero, so the
+            // order of the real additions is unchanged.
             const double* src = sums + (long)b * 2 * ld_sums;
-            for (int ch = grp * cpg + part; ch < (grp + 1) * cpg; ch += 8) {
-                a += src[ch];
-                d += src[ld_sums + ch];
+            const int c1 = (grp + 1) * cpg;
+            for (int ch = grp * cpg + part; ch < c1; ch += 8 * 5) {
+                double va[5], vd[5];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int cc = ch + 8 * u;
+                    va[u] = cc < c1 ? src[cc] : 0.0;
+                    vd[u] = cc < c1 ? src[ld_sums + cc] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    a += va[u];
+                    d += vd[u];
+                }
             }
         } else {
             for (int sp = part; sp < nsplit; sp += 8) {
