@@ -508,8 +508,7 @@ def run_vae_attention(eng: Engine, pk: NS, x, batch: int, s: int):
     c = pk.c
     out = eng.new(batch * s, c)
     mark = eng.arena.mark()
-    a = eng.groupnorm(x, batch, s, pk.gn_w, pk.gn_b, pk.gn_eps, silu=False)
-    qkv = eng.gemm(a, pk.in_proj)
+    qkv = eng.gemm(x, pk.in_proj, gn_in=dict(batch=batch, hw=s, gamma=pk.gn_w, beta=pk.gn_b, eps=pk.gn_eps, silu=False))
     o = eng.new(batch * s, c)
     for i in range(batch):
         m2 = eng.arena.mark()
