@@ -133,7 +133,13 @@ def main():
     ap.add_argument("--sampler", default="ddpm", choices=["ddpm", "k_euler_cfg"],
                     help="k_euler_cfg: the scripted loop of the reference's inference.py - 50 K-Euler steps with "
                          "classifier-free guidance (model batch doubled); a side measurement, not the headline metric")
+    ap.add_argument("--fp32-split", action="store_true",
+                    help="side measurement, NOT the headline metric: the fp32 configurations with the engine's opt-in "
+                         "split-bf16 product mode (DM_FP32_SPLIT=1: a_hi w_hi + a_lo w_hi + a_hi w_lo on the bf16 MFMA, "
+                         "about 16 bits of each operand instead of 24); reported as dtype 'f32 operands as 2 x bf16'")
     args = ap.parse_args()
+    if args.fp32_split:
+        os.environ["DM_FP32_SPLIT"] = "1"  # read when the engine is created
 
     cfg = dict(CONFIGS[args.config])
     if args.batch:
@@ -234,6 +240,9 @@ def main():
         conv = prof["conv3x3"]
         tflops = conv["work"] / (conv["ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[cfg["dtype"]]
+        split = args.fp32_split and cfg["dtype"] == "f32"
+        if split:
+            peak = PEAK_TFLOPS["bf16"] / 3  # three bf16 products per fp32 product (conv / GEMM classes; attention stays fp32)
         # every kernel class of one U-Net forward against its roofline: MFMA classes (algorithmic 2*M*N*K flops) vs the
         # dense MFMA peak of the dtype, the others (algorithmic bytes: one read + one write) vs 8 TB/s of HBM
         classes = {}
@@ -256,14 +265,16 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if cfg.get("sharded") else "weak",
             "vs_baseline": None,
-            "dtype": cfg["dtype"],
+            "dtype": (cfg["dtype"] if not split
+                      else "f32 operands as 2 x bf16 (3 products, fp32 accumulation): reduced precision, side measurement"),
             "data": "synthetic (deterministic random-init weights, "
                     + ("CLIP context from random token ids, " if clip is not None else "seeded random context, ")
                     + "device-generated noise)",
             "config": {"workload": cfg["name"], "batch_per_gpu": B, "global_batch": global_batch,
                        "latent": f"{HW}x{HW}", "ddpm_steps": T, "hip_graph": sched.use_hip_graph,
                        "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_igemm_kernel" + (" + conv3x3_wide_kernel" if cfg["dtype"] == "bf16" else " + conv3x3_gn_kernel"),
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_igemm_kernel" + (" + conv3x3_wide_kernel" if cfg["dtype"] == "bf16"
+                                                                          else " + conv3x3_gn_kernel" if not split else " (conv3x3_split_kernel)"),
                          "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(tflops / peak, 4), "traffic": pmc_traffic(args.config, B, HW),
                          "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, separate passes)",

@@ -59,6 +59,7 @@ class GemmDesc(C.Structure):
         ("pad_hi_only", C.c_int),
         ("gn_sums", C.c_void_p), ("ld_gn", C.c_long), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
         ("gn_eps", C.c_float), ("gn_silu", C.c_int), ("gn_groups", C.c_int),
+        ("w_split", C.c_int),
     ]
 
 
@@ -133,7 +134,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dm_abi_version() != 8:
+        if handle.dm_abi_version() != 9:
             raise RuntimeError("libdm_hip.so ABI version mismatch; rebuild with `python build.py`")
         _lib = handle
     return _lib

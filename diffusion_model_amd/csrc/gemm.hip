@@ -419,6 +419,51 @@ __device__ __forceinline__ void mma_tile_gn(f32x4 (&acc)[FM][4], const char* sa,
     }
 }
 
+// ---- fp32 activations x split-bf16 weights on the bf16 MFMA (opt-in mode, DmGemmDesc.w_split) --------------------
+// The weight image of this mode holds, per packed row and k-tile of 32 values, 32 bf16 "hi" terms followed by 32 bf16
+// "lo" terms (w ~ hi + lo, lo = bf16(w - hi)): the same 128 bytes per row and k-tile as the fp32 image, so staging is
+// unchanged.  The activations stay fp32 in memory and LDS; a lane takes the eight consecutive k values of its lane
+// group (two 16-byte chunks), splits them the same way in registers and issues three 16x16x32 MFMAs per output
+// fragment: a_hi.w_hi + a_lo.w_hi + a_hi.w_lo with fp32 accumulation (the lo.lo term, 2^-16 of a product, is dropped).
+// One k-tile is then 12 bf16 MFMAs per 16 x 64 wave tile (192 cycles) instead of 32 exact-fp32 ones (1024 cycles).
+template <int FM>
+__device__ __forceinline__ void mma_tile_split(f32x4 (&acc)[FM][4], const char* sa, const char* sw, int arow0, int wrow0,
+                                               int fr, int fq) {
+    u32x4 a0[FM], a1[FM], wh[4], wl[4];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        a0[i] = *reinterpret_cast<const u32x4*>(sa + swz(arow0 + i * 16 + fr, 2 * fq));
+        a1[i] = *reinterpret_cast<const u32x4*>(sa + swz(arow0 + i * 16 + fr, 2 * fq + 1));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        wh[j] = *reinterpret_cast<const u32x4*>(sw + swz(wrow0 + j * 16 + fr, fq));
+        wl[j] = *reinterpret_cast<const u32x4*>(sw + swz(wrow0 + j * 16 + fr, 4 + fq));
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f[e] = __uint_as_float(a0[i][e]);
+            f[4 + e] = __uint_as_float(a1[i][e]);
+        }
+        u32x4 ah, al;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t h = pack_bf16x2(f[2 * q], f[2 * q + 1]);
+            ah[q] = h;
+            al[q] = pack_bf16x2(f[2 * q] - __uint_as_float(h << 16), f[2 * q + 1] - __uint_as_float(h & 0xffff0000u));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Mma16<bf16_t>::mma(acc[i][j], wh[j], ah);
+            Mma16<bf16_t>::mma(acc[i][j], wh[j], al);
+            Mma16<bf16_t>::mma(acc[i][j], wl[j], ah);
+        }
+    }
+}
+
 // mean and 1/sqrt(var + eps) of the rows this lane will finish, from the per-row (sum, sumsq) that the producer
 // of A accumulated.  The difference of the two moments is taken in fp64 (cancellation), the rest in fp32.
 template <int FM>
@@ -718,8 +763,10 @@ template <int LOADS, int MAXY> __device__ __forceinline__ void wait_young(int yo
 // ------------------------------------------------------------------------------------------------
 // direct-to-LDS main loop
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool CONV, bool EARLY = false, bool GN = false>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool CONV, bool EARLY = false, bool GN = false,
+          bool SPLIT = false>
 __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
+    static_assert(!SPLIT || (sizeof(T) == 4 && !EARLY && !GN), "split-bf16 weights go with the plain fp32 ring loop");
     static_assert(!EARLY || STAGES == 2, "the early-refill loop runs on two LDS buffers");
     static_assert(!GN || (sizeof(T) == 4 && !EARLY), "fragment-side GroupNorm exists for the fp32 ring loop only");
     constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -1028,6 +1075,8 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
                     gn_c0 = 0;
                     ++gn_tap;
                 }
+            } else if constexpr (SPLIT) {
+                mma_tile_split<FM>(acc, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq);
             } else {
                 mma_tile<T, FM>(acc, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq);
             }
@@ -1145,6 +1194,18 @@ template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_M* WAVES_N, STAGES)) void conv3x3_igemm_kernel(
     GemmArgs p) {
     gemm_dma_body<T, BM, BN, WAVES_M, WAVES_N, STAGES, true, EARLY>(p);
+}
+
+// fp32 activations, split-bf16 weight image (mma_tile_split)
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_M* WAVES_N, STAGES)) void gemm_split_kernel(
+    GemmArgs p) {
+    gemm_dma_body<float, BM, BN, WAVES_M, WAVES_N, STAGES, false, false, false, true>(p);
+}
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_M* WAVES_N, STAGES)) void conv3x3_split_kernel(
+    GemmArgs p) {
+    gemm_dma_body<float, BM, BN, WAVES_M, WAVES_N, STAGES, true, false, false, true>(p);
 }
 
 // fp32 with the GroupNorm of the A operand applied to the fragments (conv: + SiLU; dense: affine only)
@@ -1706,6 +1767,33 @@ int launch_gn_typed(const GemmArgs& a, int cfg, hipStream_t s) {
     }
 }
 
+template <int BM, int BN, int WM, int WN, int ST> int launch_split(const GemmArgs& a, hipStream_t s) {
+    static DmLdsAttr done, done_conv;
+    const TileInfo t{BM, BN, WM * WN * 64, ST * (BM + BN) * 128};
+    if (a.conv) return launch_kernel(conv3x3_split_kernel<BM, BN, WM, WN, ST>, done_conv, t, a, s);
+    return launch_kernel(gemm_split_kernel<BM, BN, WM, WN, ST>, done, t, a, s);
+}
+bool split_tile(int cfg) {
+    switch (cfg) {
+        case DM_TILE_D128x128_S2: case DM_TILE_D64x128_S3: case DM_TILE_D64x64_S4: case DM_TILE_D32x64_S4:
+        case DM_TILE_D256x64_S2: case DM_TILE_D128x64_S2: case DM_TILE_D64x64_S2:
+            return true;
+        default: return false;
+    }
+}
+int launch_split_typed(const GemmArgs& a, int cfg, hipStream_t s) {
+    switch (cfg) {
+        case DM_TILE_D128x128_S2: return launch_split<128, 128, 2, 2, 2>(a, s);
+        case DM_TILE_D64x128_S3: return launch_split<64, 128, 2, 2, 3>(a, s);
+        case DM_TILE_D64x64_S4: return launch_split<64, 64, 4, 1, 4>(a, s);
+        case DM_TILE_D32x64_S4: return launch_split<32, 64, 2, 1, 4>(a, s);
+        case DM_TILE_D256x64_S2: return launch_split<256, 64, 4, 1, 2>(a, s);
+        case DM_TILE_D128x64_S2: return launch_split<128, 64, 4, 1, 2>(a, s);
+        case DM_TILE_D64x64_S2: return launch_split<64, 64, 4, 1, 2>(a, s);
+        default: return DM_ERR_ARG;
+    }
+}
+
 // 256 x 256 ping-pong tile: bf16 only (exact-fp32 MFMA is 16x slower per operand byte: operand traffic is not its limit)
 template <typename T> int launch_wide(const GemmArgs& a, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
@@ -2001,6 +2089,10 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     // fused statistics: a wave's rows must lie inside one sample, and the separate split-K reduction
     // launch does not produce them
     if (d->stats && (d->rows_per_batch % tile_wave_rows(tile) || d->m % d->rows_per_batch || splitk > 1)) return DM_ERR_ARG;
+    if (d->w_split) {
+        // split-bf16 weight image: fp32 problems on the plain direct-to-LDS ring loop
+        if (d->dtype != DM_F32 || !split_tile(tile) || d->gn_sums) return DM_ERR_ARG;
+    }
     int gn_c = 0;
     if (d->gn_sums) {
         // GroupNorm of A inside the launch: every tile lies in one sample, whole k-tiles of normalised channels
@@ -2070,7 +2162,8 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     a.gn_c = gn_c;
 
     int rc = d->gn_sums ? launch_gn_typed(a, tile, stream)
-                        : (d->dtype == DM_F32 ? launch_typed<float>(a, tile, stream) : launch_typed<bf16_t>(a, tile, stream));
+             : d->w_split ? launch_split_typed(a, tile, stream)
+                          : (d->dtype == DM_F32 ? launch_typed<float>(a, tile, stream) : launch_typed<bf16_t>(a, tile, stream));
     if (rc != DM_OK) return rc;
     if (splitk > 1) {
         const long total = (long)a.M * (a.N >> 2);

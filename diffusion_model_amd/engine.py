@@ -71,7 +71,7 @@ class Arena:
 
 class PackedWeight:
     """Weight matrix in the GEMM kernel's layout plus its fp32 bias."""
-    __slots__ = ("w", "n", "k", "npad", "kpad", "bias", "geglu", "conv_cin", "colsum", "ln_eps", "skip_cin")
+    __slots__ = ("w", "n", "k", "npad", "kpad", "bias", "geglu", "conv_cin", "colsum", "ln_eps", "skip_cin", "split")
 
     def __init__(self, w, n, k, npad, kpad, bias, geglu=False, conv_cin=0):
         self.w, self.n, self.k, self.npad, self.kpad = w, n, k, npad, kpad
@@ -79,6 +79,7 @@ class PackedWeight:
         self.colsum = None  # set when a LayerNorm is folded in: sum over k of every packed row (fp32)
         self.ln_eps = 0.0
         self.skip_cin = 0  # conv3x3 packed with a pointwise term over a second tensor: its channel count
+        self.split = False  # fp32 weights stored as bf16 (hi | lo) pairs per k-tile (Engine.split_bf16)
 
 
 class Engine:
@@ -141,6 +142,12 @@ class Engine:
         # 64 x 64 convolution measured 93 us as GroupNorm kernel + convolution against 114 us with the map inside.  The
         # projections behind an AttentionBlock's GroupNorm (no SiLU, no taps) gain 1.1-1.2x and are always taken.
         self.fuse_gn_conv_max_n = int(os.environ.get("DM_FUSE_GN_CONV_MAX_N", "64"))
+        # Opt-in arithmetic mode of the fp32 engine (DM_FP32_SPLIT=1; off by default: the default is the reference's
+        # arithmetic, exact-fp32 MFMA).  Weights are packed as two bf16 terms per value and the GEMM / conv kernels
+        # form a_hi w_hi + a_lo w_hi + a_hi w_lo on the bf16 MFMA with the fp32 activations split in registers: about
+        # 16 bits of each operand instead of 24, fp32 accumulation, 16x the matrix rate per product.  Tensors, layouts,
+        # attention, norms and the scheduler stay fp32.
+        self.split_bf16 = dtype == torch.float32 and os.environ.get("DM_FP32_SPLIT", "0") == "1"
         self.profile: Optional[dict] = None  # kernel class -> [events...] when profiling
         self._order_cache: Dict[Tuple[int, int, bool], torch.Tensor] = {}
         self.tile_override: Optional[Tuple[int, int]] = None
@@ -276,6 +283,17 @@ class Engine:
         wp[valid, :k] = w2d.detach().to(self.device)[order[valid]].to(self.dtype)
         b = None if bias is None else bias.detach().to(device=self.device, dtype=torch.float32).contiguous()
         pw = PackedWeight(None, n, k, npad, kpad, b, geglu, conv_cin)
+        if self.split_bf16:
+            # per k-tile of 32 values: 32 bf16 hi terms, then 32 bf16 lo terms - 128 bytes, as in the fp32 image
+            hi = wp.to(torch.bfloat16)
+            lo = (wp - hi.float()).to(torch.bfloat16)
+            if rowsum:
+                pw.colsum = (hi.float() + lo.float()).sum(dim=1).contiguous()
+            nkt = kpad // self.bk
+            img = torch.cat([hi.view(npad, nkt, self.bk), lo.view(npad, nkt, self.bk)], dim=2)
+            pw.w = img.view(npad // 64, 64, nkt, 2 * self.bk).permute(0, 2, 1, 3).contiguous()
+            pw.split = True
+            return pw
         if rowsum:  # per packed row, of the values the MFMA really sees (after rounding to the engine dtype)
             pw.colsum = wp.float().sum(dim=1).contiguous()
         # blocked image [npad/64][kpad/bk][64][bk]: the k-tile of a 64-row group is one contiguous 8 KiB piece
@@ -362,7 +380,8 @@ class Engine:
             geom_ok = conv is None or (conv.get("stride", 1) == 1 and not conv.get("up", 0)
                                        and not conv.get("pad_hi_only", 0) and conv["hin"] == conv["hout"]
                                        and conv["win"] == conv["wout"] and conv["hout"] * conv["wout"] == gn_in["hw"])
-            if (self.fuse_gn_apply and self.dtype == torch.float32 and geom_ok and ln_in is None and a2 is None
+            if (self.fuse_gn_apply and not pw.split and self.dtype == torch.float32 and geom_ok and ln_in is None
+                    and a2 is None
                     and (conv is None or pw.n <= self.fuse_gn_conv_max_n)
                     and (conv is not None) == bool(gn_in["silu"]) and c_gn % 32 == 0 and c_gn <= 1280):
                 gn_rec = self._gn_lookup(a, gn_in["batch"])
@@ -415,6 +434,7 @@ class Engine:
         if residual is not None:
             d.r, d.ldr = residual.data_ptr(), residual.stride(0)
         d.m, d.n, d.k, d.npad, d.kpad, d.dtype = m, pw.n, pw.k, pw.npad, pw.kpad, self.dm
+        d.w_split = int(pw.split)
         tile, sk = C.c_int(0), C.c_int(1)
         if self.tile_override is not None:
             tile.value, sk.value = self.tile_override
@@ -426,6 +446,8 @@ class Engine:
             # operand) are part of the key: a tile chosen for one use is never silently applied to another
             key = (m, pw.n, pw.k, d.conv, d.stride, d.up, d.epi, residual is not None, rowbias is not None, no_legacy,
                    gn_batch > 0 and self.fuse_gn_stats, bool(d.a2), d.pad_hi_only)
+            if pw.split:
+                key = key + ("w_split",)  # other kernels, other winners
             if gn_rec is not None:
                 # the fragment-side GroupNorm changes the LDS footprint and the loop: its own entry
                 key = key + ("gn_in",)

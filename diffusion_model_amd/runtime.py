@@ -40,7 +40,7 @@ def _signature(module: torch.nn.Module):
 def cached_pack(module: torch.nn.Module, eng: Engine, builder):
     """Pack once per (engine, parameter version); repack if any parameter was modified in place or moved."""
     cache = module.__dict__.setdefault("_dm_pack_cache", {})
-    sig = _signature(module)
+    sig = (_signature(module), eng.split_bf16)  # the arithmetic mode decides the weight image
     hit = cache.get(id(eng))
     if hit is None or hit[0] != sig:
         hit = (sig, builder(module, eng))

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 8
+#define DM_ABI_VERSION 9
 
 #define DM_F32 0
 #define DM_BF16 1
@@ -152,6 +152,12 @@ typedef struct DmGemmDesc {
     float gn_eps;
     int gn_silu;
     int gn_groups;
+    /* Opt-in arithmetic mode for fp32 problems (0 = exact-fp32 MFMA, the default): `w` is a split-bf16 image - per
+     * packed row and k-tile of 32 values, 32 bf16 hi terms followed by 32 bf16 lo terms (w ~ hi + lo, lo = bf16(w - hi));
+     * same blocking and bytes as the fp32 image - and the launch forms a_hi w_hi + a_lo w_hi + a_hi w_lo on the bf16
+     * MFMA with the fp32 activations split in registers (fp32 accumulation; error of a product ~2^-16 instead of 2^-24).
+     * Direct-to-LDS tiles, not together with gn_sums.  No counterpart in the reference, which computes in fp32. */
+    int w_split;
 } DmGemmDesc;
 
 int dm_gemm(const DmGemmDesc* d, hipStream_t stream);

@@ -475,3 +475,34 @@ def test_ddim_sample_matches_oracle(model_f32, dev):
             d.use_hip_graph = use_graph
             got = d.sample(model_f32, (1, 4, 16, 16), ctx.to(dev), torch.Generator().manual_seed(9), dev)
             assert max_rel(got, x) < F32, (eta, use_graph)
+
+
+def test_fp32_split_bf16_mode_forward_and_trajectory(dev):
+    """The opt-in split-bf16 product mode of the fp32 engine (DM_FP32_SPLIT / Engine.split_bf16) on the whole model:
+    eps of one forward and the 5-step config-1 trajectory (eager, capture + replay) against the vectors recorded from the
+    reference.  The mode is not the reference's arithmetic (about 16 bits of each GEMM / conv operand); stated bound:
+    1e-4 on eps and on every latent - ten times inside the 1e-3 the fp32 path is held to."""
+    from diffusion_model_amd.engine import Engine
+    eng = Engine.get(dev, torch.float32)
+    prev, eng.split_bf16 = eng.split_bf16, True
+    try:
+        model = deterministic_fill_(Diffusion(), seed=0).to(dev).eval()  # packs its weights in the mode that is on now
+        g = load_golden("model")
+        ctx1 = torch.as_tensor(g["context_seed1"]).to(dev)
+        temb = sched_ref.timestep_embedding(torch.tensor([37]), 320).to(dev)
+        errs = {}
+        for hw in (32, 64):
+            out = model(tin(f"model.x{hw}", (1, 4, hw, hw)).to(dev), ctx1, temb)
+            errs[f"eps_{hw}"] = max_rel(out, g[f"eps_{hw}"])
+        sched = DDPMScheduler(num_train_timesteps=5)
+        for use_graph in (False, True):
+            sched.use_hip_graph = use_graph
+            trace = []
+            x_T = torch.as_tensor(g["traj_xT"]).to(dev)
+            noises = [n.to(dev) for n in torch.as_tensor(g["traj_noises"])]
+            sched.sample_from_noise(model, x_T, noises, ctx1, trace=trace)
+            errs[f"latents graph={use_graph}"] = max(max_rel(trace[i], g["traj_latents"][i]) for i in range(5))
+        print("split-bf16 mode errors:", {k: f"{v:.2e}" for k, v in errs.items()})
+        assert max(errs.values()) < 1e-4, errs
+    finally:
+        eng.split_bf16 = prev

@@ -252,6 +252,63 @@ def test_gemm_groupnorm_on_a_fragments(dev, tile, sk, kind):
     assert max_rel(out.float().cpu(), ref) < 2e-5
 
 
+SPLIT_TILES = (_lib.TILE_D128x128_S2, _lib.TILE_D64x128_S3, _lib.TILE_D64x64_S4, _lib.TILE_D32x64_S4, _lib.TILE_D256x64_S2,
+               _lib.TILE_D128x64_S2, _lib.TILE_D64x64_S2)
+
+
+@pytest.mark.parametrize("tile", SPLIT_TILES)
+@pytest.mark.parametrize("sk", [1, -9, -70])
+@pytest.mark.parametrize("kind", ["dense", "dense+second", "conv", "conv+pointwise"])
+def test_gemm_split_bf16_weight_mode(dev, tile, sk, kind):
+    """The fp32 engine's opt-in product mode (Engine.split_bf16): weights packed as bf16 (hi | lo) pairs, activations
+    split in registers, three bf16 MFMA products per fp32 product.  Not the reference's arithmetic: about 16 bits of
+    each operand, so the bound here is 3e-5 of the output range instead of the 2e-5 of the exact-fp32 kernels."""
+    eng = Engine.get(dev, torch.float32)
+    eng.reset()
+    prev, eng.split_bf16 = eng.split_bf16, True
+    eng.tile_override = (tile, sk)
+    try:
+        if kind.startswith("dense"):
+            m, k, n = 200, 640, 320
+            a = tin("sp.a", (m, k)); w = tin("sp.w", (n, k), scale=1 / math.sqrt(k)); b = tin("sp.b", (n,))
+            r = tin("sp.r", (m, n))
+            lin = torch.nn.Linear(k, n)
+            with torch.no_grad():
+                lin.weight.copy_(w); lin.bias.copy_(b)
+            pw = eng.pack_linear(lin)
+            assert pw.split
+            if kind == "dense+second":
+                pw.skip_cin = 128  # the last 128 columns of the logical A row live in a second tensor
+                out = eng.gemm(up(eng, a[:, :k - 128]), pw, a2=up(eng, a[:, k - 128:]), residual=up(eng, r))
+            else:
+                out = eng.gemm(up(eng, a), pw, residual=up(eng, r))
+            ref = (a.double() @ w.double().t() + b.double() + r.double()).float()
+        else:
+            bsz, h, wd, c, n = 2, 9, 8, 64, 128
+            m = bsz * h * wd
+            a = tin("sp.ca", (m, c)); w = tin("sp.cw", (n, c, 3, 3), scale=1 / math.sqrt(9 * c)); b = tin("sp.cb", (n,))
+            conv = torch.nn.Conv2d(c, n, 3, padding=1)
+            with torch.no_grad():
+                conv.weight.copy_(w); conv.bias.copy_(b)
+            ref = F.conv2d(a.double().reshape(bsz, h, wd, c).permute(0, 3, 1, 2), w.double(), b.double(), padding=1)
+            geom = dict(batch=bsz, hin=h, win=wd, hout=h, wout=wd, cin_real=c)
+            if kind == "conv+pointwise":
+                c2 = 32
+                ws = tin("sp.sw", (n, c2, 1, 1), scale=1 / math.sqrt(c2)); s_in = tin("sp.s", (m, c2))
+                skip = torch.nn.Conv2d(c2, n, 1, bias=False)
+                with torch.no_grad():
+                    skip.weight.copy_(ws)
+                ref = ref + F.conv2d(s_in.double().reshape(bsz, h, wd, c2).permute(0, 3, 1, 2), ws.double())
+                out = eng.gemm(up(eng, a), eng.pack_conv3x3(conv, skip=skip), conv=dict(geom, skip=up(eng, s_in)))
+            else:
+                out = eng.gemm(up(eng, a), eng.pack_conv3x3(conv), conv=geom)
+            ref = ref.permute(0, 2, 3, 1).reshape(m, n).float()
+    finally:
+        eng.tile_override = None
+        eng.split_bf16 = prev
+    assert max_rel(out.float().cpu(), ref) < 3e-5
+
+
 @pytest.mark.parametrize("geglu", [False, True])
 @pytest.mark.parametrize("tile,sk", [(_lib.TILE_AUTO, 1), (_lib.TILE_D128x128_S2, -40), (_lib.TILE_D64x64_S2, 1),
                                      (_lib.TILE_D256x256_S2, 1), (_lib.TILE_D256x256_S2, -40)])

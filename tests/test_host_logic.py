@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/dm_hip.h but not exported"
     assert sorted(_lib.EXPORTED_SYMBOLS) == names, "ctypes prototypes and header are out of sync"
-    assert handle.dm_abi_version() == 8
+    assert handle.dm_abi_version() == 9
 
 
 def test_pack_order_is_a_permutation_with_lane_contiguous_columns():
@@ -233,8 +233,10 @@ def test_shipped_tile_table_is_well_formed():
         assert len(rows) > 100
         for key, (tile, split) in rows.items():
             k = ast.literal_eval(key)
-            # 13 fields, plus the marker of the launches that normalise their A operand themselves (fp32)
-            assert isinstance(k, tuple) and (len(k) == 13 or (len(k) == 14 and k[13] == "gn_in" and "float32" in dtype))
+            # 13 fields, plus (fp32) the marker of the launches that normalise their A operand themselves or of the
+            # opt-in split-bf16 product mode
+            assert isinstance(k, tuple) and (len(k) == 13 or (len(k) == 14 and k[13] in ("gn_in", "w_split")
+                                                              and "float32" in dtype))
             assert k[0] > 0 and k[1] > 0 and k[2] > 0
             assert tile in _lib.TILE_DIMS
             assert split != 0
