@@ -85,6 +85,7 @@ _PROTOS = {
     "dm_groupnorm_noalloc": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp]),
     "dm_layernorm": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _f, _vp]),
     "dm_attention": (C.c_int, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dm_attention_split_f32": (C.c_int, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "dm_embed_tokens": (C.c_int, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp]),
     "dm_rescale": (C.c_int, [_vp, _vp, _l, _i, _f, _f, _f, _f, _i, _f, _f, _vp]),
     "dm_u8_to_images": (C.c_int, [_vp, _i, _i, _l, _f, _f, _f, _f, _vp, _i, _vp]),

@@ -41,6 +41,7 @@ struct AttnArgs {
     int causal;        // 1: key j is visible to query i only when j <= i (attention.py:35-37)
     int nqblk, nblk;   // query blocks per (batch, head); blocks in the grid
     float scale_log2;  // log2(e) / sqrt(d)
+    int split;         // fp32 only: both products as split-bf16 products on the bf16 MFMA (opt-in mode)
 };
 
 __device__ __attribute__((aligned(16))) uint32_t g_attn_zero16[4];
@@ -51,6 +52,28 @@ __device__ __attribute__((aligned(16))) uint32_t g_attn_ones_f32[4] = {0x3F80000
 #define DM_GLDS16(src, dst)                                                                         \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),          \
                                      (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+// Eight fp32 values (two 16-byte chunks) as two bf16 terms each: x ~ hi + lo, lo = bf16(x - hi).
+__device__ __forceinline__ void split8(const u32x4& x0, const u32x4& x1, u32x4& hi, u32x4& lo) {
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f[e] = __uint_as_float(x0[e]);
+        f[4 + e] = __uint_as_float(x1[e]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t h = pack_bf16x2(f[2 * q], f[2 * q + 1]);
+        hi[q] = h;
+        lo[q] = pack_bf16x2(f[2 * q] - __uint_as_float(h << 16), f[2 * q + 1] - __uint_as_float(h & 0xffff0000u));
+    }
+}
+// acc += a b with both fp32 operands given as split pairs: a_hi b_hi + a_lo b_hi + a_hi b_lo (fp32 accumulation)
+__device__ __forceinline__ void mma_split(f32x4& acc, const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl) {
+    Mma16<bf16_t>::mma(acc, ah, bh);
+    Mma16<bf16_t>::mma(acc, al, bh);
+    Mma16<bf16_t>::mma(acc, ah, bl);
+}
 
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -74,9 +97,15 @@ template <int OFF0, int OFF1> __device__ __forceinline__ void tr_read_pair(u32x2
 // summed through LDS (two small buffers, alternating per key tile), every wave forms the same probabilities and
 // multiplies them with every fourth 16-column tile of V.  Four times the blocks, a quarter of the MFMA chain per
 // wave and key tile: the deep U-Net levels at batch 1 are bound by that chain, not by throughput.
-template <typename T, int D, int QT, bool DSPLIT = false>
+// SPLIT (fp32 tensors, opt-in arithmetic mode): K, Q, V and the probabilities are split into two bf16 terms in
+// registers and both products run as three 16x16x32 bf16 MFMAs per fragment pair (hi hi + lo hi + hi lo, fp32
+// accumulation) instead of eight exact-fp32 ones.  A 32-wide k-step takes, per lane group, the group's chunk of two
+// consecutive 16-float k-steps (K Q^T) or its four keys of both 16-key blocks of the tile (V^T P^T): the same
+// permutation of k on both operands, so the LDS images and reads are those of the fp32 path.
+template <typename T, int D, int QT, bool DSPLIT = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     static_assert(!DSPLIT || QT == 1, "the head-dimension split works on one query tile per block");
+    static_assert(!SPLIT || (sizeof(T) == 4 && !DSPLIT), "split-bf16 products exist for the plain fp32 form");
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int ESZ = sizeof(T);
     constexpr int NKS = (D * ESZ + 63) / 64;   // 64-byte k-steps over the head dim
@@ -105,7 +134,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     // with the usual layout (lane group qp owns chunk qp) each of its four 16x16x4 MFMAs multiplies half padding.
     // Here lane group qp owns the two values 2*qp, 2*qp + 1 of that step instead (the same permutation of k on both
     // operands), so two MFMAs cover it: 20 instead of 24 per 16 keys.
-    constexpr bool HALF_LAST = sizeof(T) == 4 && !DSPLIT && (D % 16) == 8;
+    constexpr bool HALF_LAST = sizeof(T) == 4 && !DSPLIT && !SPLIT && (D % 16) == 8;
+    constexpr int P2 = (NKS + 1) / 2;  // SPLIT: 32-wide k-steps of K Q^T (pairs of 16-float k-steps)
     constexpr int PBUF = 4 * NKT * 64 * 16;  // DSPLIT: one buffer of partial score tiles (4 waves x NKT x 64 lanes x 16 B)
     auto ksw = [](int row) { return (row >> 1) & 3; };
     static_assert(D % EPC == 0, "head dim must be a whole number of 16-byte chunks");
@@ -214,6 +244,16 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         }
     }
 
+    [[maybe_unused]] u32x4 qh[QT][P2], ql[QT][P2];
+    if constexpr (SPLIT) {
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int s2 = 0; s2 < P2; ++s2)
+                split8(qf[qt][2 * s2], 2 * s2 + 1 < NKS ? qf[qt][2 * s2 + 1] : zero, qh[qt][s2], ql[qt][s2]);
+    }
+
     f32x4 oacc[DT][QT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -290,6 +330,29 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
                 for (int w = 1; w < 4; ++w) sum += part[(w * NKT + kt) * 64 + lane];
                 sacc[kt][0] = sum;
+            }
+        } else if constexpr (SPLIT) {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) sacc[kt][qt] = f32x4{-m_ref[qt], -m_ref[qt], -m_ref[qt], -m_ref[qt]};
+#pragma unroll
+            for (int s2 = 0; s2 < P2; ++s2) {
+                u32x4 k0[NKT], k1[NKT];
+                load_k(2 * s2, k0);
+                if (2 * s2 + 1 < NKS) {
+                    load_k(2 * s2 + 1, k1);
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < NKT; ++kt) k1[kt] = u32x4{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    u32x4 kh, kl;
+                    split8(k0[kt], k1[kt], kh, kl);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) mma_split(sacc[kt][qt], kh, kl, qh[qt][s2], ql[qt][s2]);
+                }
             }
         } else {
 #pragma unroll
@@ -392,6 +455,25 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                     for (int qt = 0; qt < QT; ++qt) Mma16<T>::mma(oacc[dt][qt], va, pb[qt]);
                 }
             });
+        } else if constexpr (SPLIT) {
+            static_assert(!SPLIT || NKT == 2, "a tile of 32 keys is one 32-wide k-step of the second product");
+            u32x4 ph[QT], pl[QT];
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+                split8(__builtin_bit_cast(u32x4, sacc[0][qt]), __builtin_bit_cast(u32x4, sacc[NKT - 1][qt]), ph[qt], pl[qt]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                // keys 4*qp + e and 16 + 4*qp + e, e = 0..3, of column dt*16 + c
+                u32x4 v0, v1, vh, vl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v0[e] = *reinterpret_cast<const uint32_t*>(s_v + (4 * qp + e) * VPITCH + (dt * 16 + c) * 4);
+                    v1[e] = *reinterpret_cast<const uint32_t*>(s_v + (16 + 4 * qp + e) * VPITCH + (dt * 16 + c) * 4);
+                }
+                split8(v0, v1, vh, vl);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) mma_split(oacc[dt][qt], vh, vl, ph[qt], pl[qt]);
+            }
         } else {
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
@@ -445,14 +527,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     }
 }
 
-template <typename T, int D, int QT, bool DSPLIT = false> int attn_launch_qt(const AttnArgs& a, int batch, hipStream_t s) {
+template <typename T, int D, int QT, bool DSPLIT = false, bool SPLIT = false>
+int attn_launch_qt(const AttnArgs& a, int batch, hipStream_t s) {
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int NKS = (D * (int)sizeof(T) + 63) / 64, DT = (D + 15) / 16, KT = 8 * EPC;
     constexpr int VCH0 = DT * 16 / EPC;  // V image: see the kernel
     constexpr int VCH = sizeof(T) == 4 ? (VCH0 | 1) : VCH0 + (6 - VCH0 % 4) % 4;
     constexpr int LDS = 2 * (NKS * KT * 64 + (KT * VCH * 16 + 1023) / 1024 * 1024) + (DSPLIT ? 2 * 4 * (KT / 16) * 64 * 16 : 0);
     static DmLdsAttr attr_done;
-    auto kfn = attn_kernel<T, D, QT, DSPLIT>;
+    auto kfn = attn_kernel<T, D, QT, DSPLIT, SPLIT>;
     if (const int rc = dm_set_lds_attr(reinterpret_cast<const void*>(kfn), attr_done, LDS)) return rc;
     AttnArgs args = a;
     args.nqblk = DSPLIT ? (a.sq + 15) / 16 : (a.sq + 64 * QT - 1) / (64 * QT);
@@ -467,6 +550,11 @@ template <typename T, int D, int QT, bool DSPLIT = false> int attn_launch_qt(con
 template <typename T, int D> int attn_launch(const AttnArgs& a, int batch, hipStream_t s) {
     const long per64 = (long)((a.sq + 63) / 64) * a.heads * batch;
     static const int forced = getenv("DM_ATTN_QT") ? atoi(getenv("DM_ATTN_QT")) : 0;  // tuning knob
+    if constexpr (sizeof(T) == 4) {
+        // opt-in split-bf16 products: 16 rows per wave (32 measured slower: 1.58 -> 1.73 ms per forward at batch 1); the
+        // small wide-head problems keep the exact-fp32 head-dimension split below
+        if (a.split && !(D >= 160 && per64 < 128)) return attn_launch_qt<T, D, 1, false, true>(a, batch, s);
+    }
     if (forced == 1) return attn_launch_qt<T, D, 1>(a, batch, s);
     if (forced == 2) return attn_launch_qt<T, D, 2>(a, batch, s);
     if constexpr (D <= 80) {
@@ -503,10 +591,11 @@ template <typename T> int attn_dispatch(const AttnArgs& a, int batch, int d, hip
 
 }  // namespace
 
-extern "C" int dm_attention(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o,
-                            long ldo, int batch, int heads, int sq, int sk, int d, int causal, int dtype,
-                            hipStream_t stream) {
+static int attention_entry(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
+                           int batch, int heads, int sq, int sk, int d, int causal, int dtype, int split,
+                           hipStream_t stream) {
     if (!q || !k || !v || !o || batch <= 0 || heads <= 0 || sq <= 0 || sk <= 0) return DM_ERR_ARG;
+    if (split && dtype != DM_F32) return DM_ERR_ARG;
     if (causal && sq != sk) return DM_ERR_ARG;
     if (dtype != DM_F32 && dtype != DM_BF16) return DM_ERR_ARG;
     const int epc = dtype == DM_F32 ? 4 : 8;
@@ -520,5 +609,18 @@ extern "C" int dm_attention(const void* q, long ldq, const void* k, long ldk, co
     a.heads = heads; a.sq = sq; a.sk = sk;
     a.causal = causal ? 1 : 0;
     a.scale_log2 = 1.4426950408889634f / sqrtf((float)d);
+    a.split = split;
     return dtype == DM_F32 ? attn_dispatch<float>(a, batch, d, stream) : attn_dispatch<bf16_t>(a, batch, d, stream);
+}
+
+extern "C" int dm_attention(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o,
+                            long ldo, int batch, int heads, int sq, int sk, int d, int causal, int dtype,
+                            hipStream_t stream) {
+    return attention_entry(q, ldq, k, ldk, v, ldv, o, ldo, batch, heads, sq, sk, d, causal, dtype, 0, stream);
+}
+
+extern "C" int dm_attention_split_f32(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o,
+                                      long ldo, int batch, int heads, int sq, int sk, int d, int causal,
+                                      hipStream_t stream) {
+    return attention_entry(q, ldq, k, ldk, v, ldv, o, ldo, batch, heads, sq, sk, d, causal, DM_F32, 1, stream);
 }

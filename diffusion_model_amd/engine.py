@@ -739,9 +739,14 @@ class Engine:
         if out is None:
             out = self.new(batch * sq, heads * d)
         with self._prof("attention", 4.0 * batch * heads * sq * sk * d, f"b={batch} sq={sq} sk={sk} d={d}"):
-            check(self.lib.dm_attention(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
-                                        v.stride(0), out.data_ptr(), out.stride(0), batch, heads, sq, sk, d,
-                                        int(causal), self.dm, self.stream), "attention")
+            if self.split_bf16:  # the fp32 engine's opt-in product mode covers both attention products too
+                check(self.lib.dm_attention_split_f32(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
+                                                      v.stride(0), out.data_ptr(), out.stride(0), batch, heads, sq, sk,
+                                                      d, int(causal), self.stream), "attention")
+            else:
+                check(self.lib.dm_attention(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
+                                            v.stride(0), out.data_ptr(), out.stride(0), batch, heads, sq, sk, d,
+                                            int(causal), self.dm, self.stream), "attention")
         return out
 
     def embed_tokens(self, tokens: torch.Tensor, table: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:

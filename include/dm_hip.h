@@ -228,6 +228,13 @@ int dm_layernorm(const void* x, long ldx, void* y, long ldy, int rows, int c, in
  * own leading dimensions).  V is read row-major as the projection wrote it; no transposed copy. */
 int dm_attention(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
                  int batch, int heads, int sq, int sk, int d, int causal, int dtype, hipStream_t stream);
+/* dm_attention for fp32 tensors in the opt-in split-bf16 product mode (see DmGemmDesc.w_split): K, Q, V and the
+ * probabilities are split into two bf16 terms in registers and both products run on the bf16 MFMA (three products per
+ * fp32 product, fp32 accumulation, softmax in fp32).  Not the reference's arithmetic; same arguments and layouts as
+ * dm_attention with dtype DM_F32.  Small wide-head problems that dm_attention runs with its head-dimension split keep
+ * that exact-fp32 form. */
+int dm_attention_split_f32(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
+                           int batch, int heads, int sq, int sk, int d, int causal, hipStream_t stream);
 
 /* y[b][n] = sum_k f(x[b][k]) * w[n][k] + bias[n], fp32, f = SiLU when silu_in.  Replaces the
  * batch-sized Linears of the time path (src/models/embeddings.py:42-44; blocks.py:63-64). */

@@ -530,6 +530,33 @@ def test_attention(eng, d, sq, sk):
 
 
 # ------------------------------------------------------------------------------------------- time path
+@pytest.mark.parametrize("d,sq,sk", [(40, 256, 256), (40, 64, 77), (80, 100, 100), (80, 256, 77), (160, 320, 300), (64, 130, 45)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_split_bf16_mode(dev, d, sq, sk, causal):
+    """fp32 attention with both products as split-bf16 products (the engine's opt-in mode): masked key tails, causal
+    masks, every head dimension.  Bound: 1e-4 of the output range (measured 1-3.5e-5; the exact-fp32 kernel is held to
+    2e-5): the inputs here give scores of up to +-20, and a score that is off by 2^-16 of its size moves its
+    probability by that much."""
+    if causal and sq != sk:
+        pytest.skip("causal attention is square")
+    eng = Engine.get(dev, torch.float32)
+    eng.reset()
+    heads, b = 2, 2
+    q = tin("as.q", (b * sq, heads * d)) * 2; k = tin("as.k", (b * sk, heads * d)) * 2; v = tin("as.v", (b * sk, heads * d))
+    prev, eng.split_bf16 = eng.split_bf16, True
+    try:
+        out = eng.attention(up(eng, q), up(eng, k), up(eng, v), b, heads, sq, sk, d, causal=causal)
+    finally:
+        eng.split_bf16 = prev
+    qq = q.double().reshape(b, sq, heads, d).transpose(1, 2); kk = k.double().reshape(b, sk, heads, d).transpose(1, 2)
+    vv = v.double().reshape(b, sk, heads, d).transpose(1, 2)
+    w = qq @ kk.transpose(-1, -2) / math.sqrt(d)
+    if causal:
+        w = w.masked_fill(torch.ones(sq, sk, dtype=torch.bool).triu(1), float("-inf"))
+    ref = (torch.softmax(w, -1) @ vv).transpose(1, 2).reshape(b * sq, heads * d).float()
+    assert max_rel(out.float().cpu(), ref) < 1e-4
+
+
 def test_linear_rows(dev):
     eng = Engine.get(dev, torch.float32)
     eng.arena.reset()
