@@ -133,13 +133,14 @@ def main():
     ap.add_argument("--sampler", default="ddpm", choices=["ddpm", "k_euler_cfg"],
                     help="k_euler_cfg: the scripted loop of the reference's inference.py - 50 K-Euler steps with "
                          "classifier-free guidance (model batch doubled); a side measurement, not the headline metric")
-    ap.add_argument("--fp32-split", action="store_true",
+    ap.add_argument("--fp32-split", type=int, nargs="?", const=2, default=0, choices=[0, 2, 3],
                     help="side measurement, NOT the headline metric: the fp32 configurations with the engine's opt-in "
-                         "split-bf16 product mode (DM_FP32_SPLIT=1: a_hi w_hi + a_lo w_hi + a_hi w_lo on the bf16 MFMA, "
-                         "about 16 bits of each operand instead of 24); reported as dtype 'f32 operands as 2 x bf16'")
+                         "split-bf16 product modes (DM_FP32_SPLIT): 2 = two bf16 terms per operand, three products, about "
+                         "16 bits of each operand (GEMM, conv and attention); 3 = three terms, six products, 24 bits "
+                         "(GEMM and conv; attention exact fp32); the line's dtype field says which")
     args = ap.parse_args()
     if args.fp32_split:
-        os.environ["DM_FP32_SPLIT"] = "1"  # read when the engine is created
+        os.environ["DM_FP32_SPLIT"] = str(args.fp32_split)  # read when the engine is created
 
     cfg = dict(CONFIGS[args.config])
     if args.batch:
@@ -240,9 +241,9 @@ def main():
         conv = prof["conv3x3"]
         tflops = conv["work"] / (conv["ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[cfg["dtype"]]
-        split = args.fp32_split and cfg["dtype"] == "f32"
+        split = args.fp32_split if cfg["dtype"] == "f32" else 0
         if split:
-            peak = PEAK_TFLOPS["bf16"] / 3  # three bf16 products per fp32 product (conv / GEMM classes; attention stays fp32)
+            peak = PEAK_TFLOPS["bf16"] / (3 if split == 2 else 6)  # bf16 products per fp32 product (conv / GEMM classes)
         # every kernel class of one U-Net forward against its roofline: MFMA classes (algorithmic 2*M*N*K flops) vs the
         # dense MFMA peak of the dtype, the others (algorithmic bytes: one read + one write) vs 8 TB/s of HBM
         classes = {}
@@ -265,8 +266,9 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if cfg.get("sharded") else "weak",
             "vs_baseline": None,
-            "dtype": (cfg["dtype"] if not split
-                      else "f32 operands as 2 x bf16 (3 products, fp32 accumulation): reduced precision, side measurement"),
+            "dtype": (cfg["dtype"] if not split else
+                      "f32 operands as 2 x bf16 (3 products, fp32 accumulation): reduced precision, side measurement" if split == 2
+                      else "f32 operands as 3 x bf16 (6 products, fp32 accumulation; attention exact f32): side measurement"),
             "data": "synthetic (deterministic random-init weights, "
                     + ("CLIP context from random token ids, " if clip is not None else "seeded random context, ")
                     + "device-generated noise)",

@@ -464,6 +464,56 @@ __device__ __forceinline__ void mma_tile_split(f32x4 (&acc)[FM][4], const char* 
     }
 }
 
+// Three bf16 terms per operand (x ~ hi + mid + lo: 24 bits) and the six products down to 2^-16 of the leading one:
+// hi hi + hi mid + mid hi + hi lo + mid mid + lo hi; what is dropped (mid lo, lo mid, lo lo) is 2^-24 of a product, the
+// size of an fp32 rounding.  The weight image of this form has TWO 128-byte rows per packed row and k-tile: plane 0 =
+// 32 hi terms | 32 mid terms, plane 1 = 32 lo terms | 64 bytes of zeros; in LDS plane 1 follows plane 0 (BN rows each).
+template <int FM, int BN>
+__device__ __forceinline__ void mma_tile_split3(f32x4 (&acc)[FM][4], const char* sa, const char* sw, int arow0, int wrow0,
+                                                int fr, int fq) {
+    u32x4 a0[FM], a1[FM], wh[4], wm[4], wl[4];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        a0[i] = *reinterpret_cast<const u32x4*>(sa + swz(arow0 + i * 16 + fr, 2 * fq));
+        a1[i] = *reinterpret_cast<const u32x4*>(sa + swz(arow0 + i * 16 + fr, 2 * fq + 1));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        wh[j] = *reinterpret_cast<const u32x4*>(sw + swz(wrow0 + j * 16 + fr, fq));
+        wm[j] = *reinterpret_cast<const u32x4*>(sw + swz(wrow0 + j * 16 + fr, 4 + fq));
+        wl[j] = *reinterpret_cast<const u32x4*>(sw + BN * 128 + swz(wrow0 + j * 16 + fr, fq));
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f[e] = __uint_as_float(a0[i][e]);
+            f[4 + e] = __uint_as_float(a1[i][e]);
+        }
+        u32x4 ah, am, al;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t h = pack_bf16x2(f[2 * q], f[2 * q + 1]);
+            const float r0 = f[2 * q] - __uint_as_float(h << 16), r1 = f[2 * q + 1] - __uint_as_float(h & 0xffff0000u);
+            const uint32_t m = pack_bf16x2(r0, r1);
+            ah[q] = h;
+            am[q] = m;
+            al[q] = pack_bf16x2(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // smallest terms first
+            Mma16<bf16_t>::mma(acc[i][j], wl[j], ah);
+            Mma16<bf16_t>::mma(acc[i][j], wh[j], al);
+            Mma16<bf16_t>::mma(acc[i][j], wm[j], am);
+            Mma16<bf16_t>::mma(acc[i][j], wm[j], ah);
+            Mma16<bf16_t>::mma(acc[i][j], wh[j], am);
+            Mma16<bf16_t>::mma(acc[i][j], wh[j], ah);
+        }
+    }
+}
+
 // mean and 1/sqrt(var + eps) of the rows this lane will finish, from the per-row (sum, sumsq) that the producer
 // of A accumulated.  The difference of the two moments is taken in fp64 (cancellation), the rest in fp32.
 template <int FM>
@@ -764,9 +814,12 @@ template <int LOADS, int MAXY> __device__ __forceinline__ void wait_young(int yo
 // direct-to-LDS main loop
 // ------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool CONV, bool EARLY = false, bool GN = false,
-          bool SPLIT = false>
+          int SPLIT = 0>
 __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
-    static_assert(!SPLIT || (sizeof(T) == 4 && !EARLY && !GN), "split-bf16 weights go with the plain fp32 ring loop");
+    // SPLIT: 0 = the operands' own arithmetic, 2 / 3 = fp32 problems with two / three bf16 terms per operand
+    static_assert(SPLIT == 0 || ((SPLIT == 2 || SPLIT == 3) && sizeof(T) == 4 && !EARLY && !GN),
+                  "split-bf16 weights go with the plain fp32 ring loop");
+    constexpr int WPL = SPLIT == 3 ? 2 : 1;  // 128-byte rows per packed weight row and k-tile
     static_assert(!EARLY || STAGES == 2, "the early-refill loop runs on two LDS buffers");
     static_assert(!GN || (sizeof(T) == 4 && !EARLY), "fragment-side GroupNorm exists for the fp32 ring loop only");
     constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -777,9 +830,9 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int BK = 8 * EPC;
     constexpr int A_IT = BM * 8 / NT;
-    constexpr int W_IT = BN * 8 / NT;
+    constexpr int W_IT = WPL * BN * 8 / NT;
     constexpr int LOADS = A_IT + W_IT;           // LDS-DMA instructions per thread per k-tile
-    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    constexpr int STAGE_BYTES = (BM + WPL * BN) * 128;
     static_assert(STAGES >= 2 && STAGES <= 8 && (STAGES - 2) * LOADS <= 63, "ring depth / vmcnt field");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -874,8 +927,12 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
         // costs one 64-bit add per DMA and no select.
         const char* w_ptr[W_IT];
 #pragma unroll
-        for (int it = 0; it < W_IT; ++it)
-            w_ptr[it] = p.W + w_block_offset(n0 + it * (NT / 8) + (tid >> 3), nkt, kt0) + lchunk * 16;
+        for (int it = 0; it < W_IT; ++it) {
+            // staged row vr of the W tile: plane vr / BN (one plane unless the image has three terms), weight row vr % BN
+            const int vr = it * (NT / 8) + (tid >> 3);
+            const int plane = WPL > 1 ? vr / BN : 0, wrow = n0 + vr - plane * BN;
+            w_ptr[it] = p.W + ((((long)(wrow >> 6) * nkt + kt0) * WPL + plane) * 64 + (wrow & 63)) * 128 + lchunk * 16;
+        }
         int kc = kt0 * BK + lchunk * EPC, tap = 0;
         if (CONV) {
             tap = min(kc / p.Cin, 9);  // tap 9: the appended pointwise operand (only with A2)
@@ -978,7 +1035,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
             for (int it = 0; it < W_IT; ++it) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[it],
                                                  (__attribute__((address_space(3))) void*)(sw + it * (NT * 16)), 16, 0, 0);
-                w_ptr[it] += W_KTILE_STEP;
+                w_ptr[it] += WPL * W_KTILE_STEP;
             }
         };
 
@@ -1075,7 +1132,9 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
                     gn_c0 = 0;
                     ++gn_tap;
                 }
-            } else if constexpr (SPLIT) {
+            } else if constexpr (SPLIT == 3) {
+                mma_tile_split3<FM, BN>(acc, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq);
+            } else if constexpr (SPLIT == 2) {
                 mma_tile_split<FM>(acc, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq);
             } else {
                 mma_tile<T, FM>(acc, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq);
@@ -1200,12 +1259,23 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_M* WAVES_N, STAGES)) void gemm_split_kernel(
     GemmArgs p) {
-    gemm_dma_body<float, BM, BN, WAVES_M, WAVES_N, STAGES, false, false, false, true>(p);
+    gemm_dma_body<float, BM, BN, WAVES_M, WAVES_N, STAGES, false, false, false, 2>(p);
 }
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_M* WAVES_N, STAGES)) void conv3x3_split_kernel(
     GemmArgs p) {
-    gemm_dma_body<float, BM, BN, WAVES_M, WAVES_N, STAGES, true, false, false, true>(p);
+    gemm_dma_body<float, BM, BN, WAVES_M, WAVES_N, STAGES, true, false, false, 2>(p);
+}
+// three terms per operand: the W tile takes twice the LDS
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, 2 * BN, WAVES_M* WAVES_N, STAGES)) void gemm_split3_kernel(
+    GemmArgs p) {
+    gemm_dma_body<float, BM, BN, WAVES_M, WAVES_N, STAGES, false, false, false, 3>(p);
+}
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, 2 * BN, WAVES_M* WAVES_N, STAGES)) void conv3x3_split3_kernel(
+    GemmArgs p) {
+    gemm_dma_body<float, BM, BN, WAVES_M, WAVES_N, STAGES, true, false, false, 3>(p);
 }
 
 // fp32 with the GroupNorm of the A operand applied to the fragments (conv: + SiLU; dense: affine only)
@@ -1767,8 +1837,13 @@ int launch_gn_typed(const GemmArgs& a, int cfg, hipStream_t s) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int ST> int launch_split(const GemmArgs& a, hipStream_t s) {
-    static DmLdsAttr done, done_conv;
+template <int BM, int BN, int WM, int WN, int ST> int launch_split(const GemmArgs& a, int terms, hipStream_t s) {
+    static DmLdsAttr done, done_conv, done3, done3_conv;
+    if (terms == 3) {
+        const TileInfo t3{BM, BN, WM * WN * 64, ST * (BM + 2 * BN) * 128};
+        if (a.conv) return launch_kernel(conv3x3_split3_kernel<BM, BN, WM, WN, ST>, done3_conv, t3, a, s);
+        return launch_kernel(gemm_split3_kernel<BM, BN, WM, WN, ST>, done3, t3, a, s);
+    }
     const TileInfo t{BM, BN, WM * WN * 64, ST * (BM + BN) * 128};
     if (a.conv) return launch_kernel(conv3x3_split_kernel<BM, BN, WM, WN, ST>, done_conv, t, a, s);
     return launch_kernel(gemm_split_kernel<BM, BN, WM, WN, ST>, done, t, a, s);
@@ -1781,15 +1856,15 @@ bool split_tile(int cfg) {
         default: return false;
     }
 }
-int launch_split_typed(const GemmArgs& a, int cfg, hipStream_t s) {
+int launch_split_typed(const GemmArgs& a, int cfg, int terms, hipStream_t s) {
     switch (cfg) {
-        case DM_TILE_D128x128_S2: return launch_split<128, 128, 2, 2, 2>(a, s);
-        case DM_TILE_D64x128_S3: return launch_split<64, 128, 2, 2, 3>(a, s);
-        case DM_TILE_D64x64_S4: return launch_split<64, 64, 4, 1, 4>(a, s);
-        case DM_TILE_D32x64_S4: return launch_split<32, 64, 2, 1, 4>(a, s);
-        case DM_TILE_D256x64_S2: return launch_split<256, 64, 4, 1, 2>(a, s);
-        case DM_TILE_D128x64_S2: return launch_split<128, 64, 4, 1, 2>(a, s);
-        case DM_TILE_D64x64_S2: return launch_split<64, 64, 4, 1, 2>(a, s);
+        case DM_TILE_D128x128_S2: return launch_split<128, 128, 2, 2, 2>(a, terms, s);
+        case DM_TILE_D64x128_S3: return launch_split<64, 128, 2, 2, 3>(a, terms, s);
+        case DM_TILE_D64x64_S4: return launch_split<64, 64, 4, 1, 4>(a, terms, s);
+        case DM_TILE_D32x64_S4: return launch_split<32, 64, 2, 1, 4>(a, terms, s);
+        case DM_TILE_D256x64_S2: return launch_split<256, 64, 4, 1, 2>(a, terms, s);
+        case DM_TILE_D128x64_S2: return launch_split<128, 64, 4, 1, 2>(a, terms, s);
+        case DM_TILE_D64x64_S2: return launch_split<64, 64, 4, 1, 2>(a, terms, s);
         default: return DM_ERR_ARG;
     }
 }
@@ -2091,7 +2166,7 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     if (d->stats && (d->rows_per_batch % tile_wave_rows(tile) || d->m % d->rows_per_batch || splitk > 1)) return DM_ERR_ARG;
     if (d->w_split) {
         // split-bf16 weight image: fp32 problems on the plain direct-to-LDS ring loop
-        if (d->dtype != DM_F32 || !split_tile(tile) || d->gn_sums) return DM_ERR_ARG;
+        if (d->dtype != DM_F32 || !split_tile(tile) || d->gn_sums || (d->w_split != 2 && d->w_split != 3)) return DM_ERR_ARG;
     }
     int gn_c = 0;
     if (d->gn_sums) {
@@ -2162,7 +2237,7 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     a.gn_c = gn_c;
 
     int rc = d->gn_sums ? launch_gn_typed(a, tile, stream)
-             : d->w_split ? launch_split_typed(a, tile, stream)
+             : d->w_split ? launch_split_typed(a, tile, d->w_split, stream)
                           : (d->dtype == DM_F32 ? launch_typed<float>(a, tile, stream) : launch_typed<bf16_t>(a, tile, stream));
     if (rc != DM_OK) return rc;
     if (splitk > 1) {

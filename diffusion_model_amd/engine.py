@@ -79,7 +79,7 @@ class PackedWeight:
         self.colsum = None  # set when a LayerNorm is folded in: sum over k of every packed row (fp32)
         self.ln_eps = 0.0
         self.skip_cin = 0  # conv3x3 packed with a pointwise term over a second tensor: its channel count
-        self.split = False  # fp32 weights stored as bf16 (hi | lo) pairs per k-tile (Engine.split_bf16)
+        self.split = 0  # fp32 weights stored as 2 or 3 bf16 terms per value (Engine.split_bf16); 0 = plain image
 
 
 class Engine:
@@ -147,7 +147,10 @@ class Engine:
         # form a_hi w_hi + a_lo w_hi + a_hi w_lo on the bf16 MFMA with the fp32 activations split in registers: about
         # 16 bits of each operand instead of 24, fp32 accumulation, 16x the matrix rate per product.  Tensors, layouts,
         # attention, norms and the scheduler stay fp32.
-        self.split_bf16 = dtype == torch.float32 and os.environ.get("DM_FP32_SPLIT", "0") == "1"
+        # DM_FP32_SPLIT=3: three terms per operand and six products - 24 bits of each operand, what is dropped is the
+        # size of an fp32 rounding; GEMM / conv only (attention stays on the exact-fp32 MFMA in that form).
+        mode = os.environ.get("DM_FP32_SPLIT", "0") if dtype == torch.float32 else "0"
+        self.split_bf16 = {"1": 2, "2": 2, "3": 3}.get(mode, 0)  # 0 = off; True counts as 2
         self.profile: Optional[dict] = None  # kernel class -> [events...] when profiling
         self._order_cache: Dict[Tuple[int, int, bool], torch.Tensor] = {}
         self.tile_override: Optional[Tuple[int, int]] = None
@@ -284,15 +287,28 @@ class Engine:
         b = None if bias is None else bias.detach().to(device=self.device, dtype=torch.float32).contiguous()
         pw = PackedWeight(None, n, k, npad, kpad, b, geglu, conv_cin)
         if self.split_bf16:
-            # per k-tile of 32 values: 32 bf16 hi terms, then 32 bf16 lo terms - 128 bytes, as in the fp32 image
-            hi = wp.to(torch.bfloat16)
-            lo = (wp - hi.float()).to(torch.bfloat16)
-            if rowsum:
-                pw.colsum = (hi.float() + lo.float()).sum(dim=1).contiguous()
             nkt = kpad // self.bk
-            img = torch.cat([hi.view(npad, nkt, self.bk), lo.view(npad, nkt, self.bk)], dim=2)
-            pw.w = img.view(npad // 64, 64, nkt, 2 * self.bk).permute(0, 2, 1, 3).contiguous()
-            pw.split = True
+            hi = wp.to(torch.bfloat16)
+            r1 = wp - hi.float()
+            if self.split_bf16 == 3:
+                # three terms: per k-tile two 128-byte rows, [hi | mid] and [lo | zeros], planes side by side per 64-row group
+                mid = r1.to(torch.bfloat16)
+                lo = (r1 - mid.float()).to(torch.bfloat16)
+                seen = hi.float() + mid.float() + lo.float()
+                p0 = torch.cat([hi.view(npad, nkt, self.bk), mid.view(npad, nkt, self.bk)], dim=2)
+                p1 = torch.cat([lo.view(npad, nkt, self.bk), torch.zeros_like(lo).view(npad, nkt, self.bk)], dim=2)
+                img = torch.stack([p0, p1], dim=2)  # [npad][nkt][2][64 bf16]
+                pw.w = img.view(npad // 64, 64, nkt, 2, 2 * self.bk).permute(0, 2, 3, 1, 4).contiguous()
+                pw.split = 3
+            else:
+                # two terms: per k-tile of 32 values 32 hi terms, then 32 lo terms - 128 bytes, as in the fp32 image
+                lo = r1.to(torch.bfloat16)
+                seen = hi.float() + lo.float()
+                img = torch.cat([hi.view(npad, nkt, self.bk), lo.view(npad, nkt, self.bk)], dim=2)
+                pw.w = img.view(npad // 64, 64, nkt, 2 * self.bk).permute(0, 2, 1, 3).contiguous()
+                pw.split = 2
+            if rowsum:
+                pw.colsum = seen.sum(dim=1).contiguous()
             return pw
         if rowsum:  # per packed row, of the values the MFMA really sees (after rounding to the engine dtype)
             pw.colsum = wp.float().sum(dim=1).contiguous()
@@ -447,7 +463,7 @@ class Engine:
             key = (m, pw.n, pw.k, d.conv, d.stride, d.up, d.epi, residual is not None, rowbias is not None, no_legacy,
                    gn_batch > 0 and self.fuse_gn_stats, bool(d.a2), d.pad_hi_only)
             if pw.split:
-                key = key + ("w_split",)  # other kernels, other winners
+                key = key + ("w_split" if pw.split == 2 else "w_split3",)  # other kernels, other winners
             if gn_rec is not None:
                 # the fragment-side GroupNorm changes the LDS footprint and the loop: its own entry
                 key = key + ("gn_in",)
@@ -739,7 +755,7 @@ class Engine:
         if out is None:
             out = self.new(batch * sq, heads * d)
         with self._prof("attention", 4.0 * batch * heads * sq * sk * d, f"b={batch} sq={sq} sk={sk} d={d}"):
-            if self.split_bf16:  # the fp32 engine's opt-in product mode covers both attention products too
+            if self.split_bf16 and self.split_bf16 != 3:  # the two-term product mode covers both attention products too
                 check(self.lib.dm_attention_split_f32(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
                                                       v.stride(0), out.data_ptr(), out.stride(0), batch, heads, sq, sk,
                                                       d, int(causal), self.stream), "attention")

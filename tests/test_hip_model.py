@@ -477,14 +477,16 @@ def test_ddim_sample_matches_oracle(model_f32, dev):
             assert max_rel(got, x) < F32, (eta, use_graph)
 
 
-def test_fp32_split_bf16_mode_forward_and_trajectory(dev):
-    """The opt-in split-bf16 product mode of the fp32 engine (DM_FP32_SPLIT / Engine.split_bf16) on the whole model:
+@pytest.mark.parametrize("terms,bound", [(2, 1e-4), (3, 1e-5)])
+def test_fp32_split_bf16_mode_forward_and_trajectory(dev, terms, bound):
+    """The opt-in split-bf16 product modes of the fp32 engine (DM_FP32_SPLIT / Engine.split_bf16) on the whole model:
     eps of one forward and the 5-step config-1 trajectory (eager, capture + replay) against the vectors recorded from the
-    reference.  The mode is not the reference's arithmetic (about 16 bits of each GEMM / conv operand); stated bound:
-    1e-4 on eps and on every latent - ten times inside the 1e-3 the fp32 path is held to."""
+    reference.  Neither mode is the reference's arithmetic.  Two terms per operand (about 16 bits; GEMM, conv and
+    attention): stated bound 1e-4 on eps and on every latent - ten times inside the 1e-3 the fp32 path is held to.  Three
+    terms and six products (24 bits; GEMM and conv): 1e-5, the neighbourhood of the exact-fp32 kernels (2.4e-6)."""
     from diffusion_model_amd.engine import Engine
     eng = Engine.get(dev, torch.float32)
-    prev, eng.split_bf16 = eng.split_bf16, True
+    prev, eng.split_bf16 = eng.split_bf16, terms
     try:
         model = deterministic_fill_(Diffusion(), seed=0).to(dev).eval()  # packs its weights in the mode that is on now
         g = load_golden("model")
@@ -502,7 +504,7 @@ def test_fp32_split_bf16_mode_forward_and_trajectory(dev):
             noises = [n.to(dev) for n in torch.as_tensor(g["traj_noises"])]
             sched.sample_from_noise(model, x_T, noises, ctx1, trace=trace)
             errs[f"latents graph={use_graph}"] = max(max_rel(trace[i], g["traj_latents"][i]) for i in range(5))
-        print("split-bf16 mode errors:", {k: f"{v:.2e}" for k, v in errs.items()})
-        assert max(errs.values()) < 1e-4, errs
+        print(f"split-bf16 mode, {terms} terms:", {k: f"{v:.2e}" for k, v in errs.items()})
+        assert max(errs.values()) < bound, errs
     finally:
         eng.split_bf16 = prev

@@ -259,13 +259,16 @@ SPLIT_TILES = (_lib.TILE_D128x128_S2, _lib.TILE_D64x128_S3, _lib.TILE_D64x64_S4,
 @pytest.mark.parametrize("tile", SPLIT_TILES)
 @pytest.mark.parametrize("sk", [1, -9, -70])
 @pytest.mark.parametrize("kind", ["dense", "dense+second", "conv", "conv+pointwise"])
-def test_gemm_split_bf16_weight_mode(dev, tile, sk, kind):
+@pytest.mark.parametrize("terms", [2, 3])
+def test_gemm_split_bf16_weight_mode(dev, tile, sk, kind, terms):
     """The fp32 engine's opt-in product mode (Engine.split_bf16): weights packed as bf16 (hi | lo) pairs, activations
     split in registers, three bf16 MFMA products per fp32 product.  Not the reference's arithmetic: about 16 bits of
-    each operand, so the bound here is 3e-5 of the output range instead of the 2e-5 of the exact-fp32 kernels."""
+    each operand, so the bound here is 3e-5 of the output range instead of the 2e-5 of the exact-fp32 kernels.  With
+    three terms per operand and six products the result is held to 3e-6: what that form drops is the size of an fp32
+    rounding, and the exact-fp32 kernel itself is 0.6-1.4e-6 from an fp64 product on these shapes."""
     eng = Engine.get(dev, torch.float32)
     eng.reset()
-    prev, eng.split_bf16 = eng.split_bf16, True
+    prev, eng.split_bf16 = eng.split_bf16, terms
     eng.tile_override = (tile, sk)
     try:
         if kind.startswith("dense"):
@@ -276,7 +279,7 @@ def test_gemm_split_bf16_weight_mode(dev, tile, sk, kind):
             with torch.no_grad():
                 lin.weight.copy_(w); lin.bias.copy_(b)
             pw = eng.pack_linear(lin)
-            assert pw.split
+            assert pw.split == terms
             if kind == "dense+second":
                 pw.skip_cin = 128  # the last 128 columns of the logical A row live in a second tensor
                 out = eng.gemm(up(eng, a[:, :k - 128]), pw, a2=up(eng, a[:, k - 128:]), residual=up(eng, r))
@@ -306,7 +309,7 @@ def test_gemm_split_bf16_weight_mode(dev, tile, sk, kind):
     finally:
         eng.tile_override = None
         eng.split_bf16 = prev
-    assert max_rel(out.float().cpu(), ref) < 3e-5
+    assert max_rel(out.float().cpu(), ref) < (3e-5 if terms == 2 else 3e-6)
 
 
 @pytest.mark.parametrize("geglu", [False, True])
