@@ -142,7 +142,7 @@ class Engine:
         # 64 x 64 convolution measured 93 us as GroupNorm kernel + convolution against 114 us with the map inside.  The
         # projections behind an AttentionBlock's GroupNorm (no SiLU, no taps) gain 1.1-1.2x and are always taken.
         self.fuse_gn_conv_max_n = int(os.environ.get("DM_FUSE_GN_CONV_MAX_N", "64"))
-        # Opt-in arithmetic mode of the fp32 engine (DM_FP32_SPLIT=1; off by default: the default is the reference's
+        # Opt-in arithmetic modes of the fp32 engine (DM_FP32_SPLIT=2, also written 1; off by default: the default is the reference's
         # arithmetic, exact-fp32 MFMA).  Weights are packed as two bf16 terms per value and the GEMM / conv kernels
         # form a_hi w_hi + a_lo w_hi + a_hi w_lo on the bf16 MFMA with the fp32 activations split in registers: about
         # 16 bits of each operand instead of 24, fp32 accumulation, 16x the matrix rate per product.  Tensors, layouts,
@@ -467,10 +467,7 @@ class Engine:
             if gn_rec is not None:
                 # the fragment-side GroupNorm changes the LDS footprint and the loop: its own entry
                 key = key + ("gn_in",)
-                d.gn_sums, d.ld_gn = gn_rec["stats_ptr"], gn_rec["ld"]
-                d.gn_gamma, d.gn_beta = gn_in["gamma"].data_ptr(), gn_in["beta"].data_ptr()
-                d.gn_eps, d.gn_silu, d.gn_groups = gn_in["eps"], int(gn_in["silu"]), gn_in.get("groups", 32)
-                d.rows_per_batch = gn_in["hw"]
+                self._bind_gn(d, gn_rec, gn_in)
             best = self.tuned.get(key)
             if best is None and self.autotune and not self.arena.frozen and self.profile is None:
                 best = self._tune(d, key, legacy=not no_legacy)
@@ -483,10 +480,7 @@ class Engine:
         d.tile, d.splitk = tile.value, sk.value
         if gn_rec is not None:
             if self.tile_override is not None:
-                d.gn_sums, d.ld_gn = gn_rec["stats_ptr"], gn_rec["ld"]
-                d.gn_gamma, d.gn_beta = gn_in["gamma"].data_ptr(), gn_in["beta"].data_ptr()
-                d.gn_eps, d.gn_silu, d.gn_groups = gn_in["eps"], int(gn_in["silu"]), gn_in.get("groups", 32)
-                d.rows_per_batch = gn_in["hw"]
+                self._bind_gn(d, gn_rec, gn_in)
             if not self.lib.dm_gemm_gn_supported(self.dm, tile.value, d.conv, a.shape[1], d.gn_groups, gn_in["hw"], sk.value):
                 # the chosen tile has no fragment-side form for this shape: normalise with the stand-alone kernel
                 a = self._gn_unfused(a, gn_in)
@@ -528,6 +522,14 @@ class Engine:
                         + (f" s={d.stride} up={d.up}" if conv is not None else "")):
             check(self.lib.dm_gemm(C.byref(d), self.stream), klass)
         return out
+
+    @staticmethod
+    def _bind_gn(d: GemmDesc, rec: dict, gn_in: dict):
+        """Descriptor fields of the fragment-side GroupNorm: the producer's sums and the affine parameters."""
+        d.gn_sums, d.ld_gn = rec["stats_ptr"], rec["ld"]
+        d.gn_gamma, d.gn_beta = gn_in["gamma"].data_ptr(), gn_in["beta"].data_ptr()
+        d.gn_eps, d.gn_silu, d.gn_groups = gn_in["eps"], int(gn_in["silu"]), gn_in.get("groups", 32)
+        d.rows_per_batch = gn_in["hw"]
 
     def _gn_unfused(self, a: torch.Tensor, gn_in: dict) -> torch.Tensor:
         return self.groupnorm(a, gn_in["batch"], gn_in["hw"], gn_in["gamma"], gn_in["beta"], gn_in["eps"],
