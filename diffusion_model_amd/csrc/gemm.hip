@@ -422,9 +422,11 @@ __device__ __forceinline__ void mma_tile_gn(f32x4 (&acc)[FM][4], const char* sa,
 // ---- fp32 activations x split-bf16 weights on the bf16 MFMA (opt-in mode, DmGemmDesc.w_split) --------------------
 // The weight image of this mode holds, per packed row and k-tile of 32 values, 32 bf16 "hi" terms followed by 32 bf16
 // "lo" terms (w ~ hi + lo, lo = bf16(w - hi)): the same 128 bytes per row and k-tile as the fp32 image, so staging is
-// unchanged.  The activations stay fp32 in memory and LDS; a lane takes the eight consecutive k values of its lane
-// group (two 16-byte chunks), splits them the same way in registers and issues three 16x16x32 MFMAs per output
-// fragment: a_hi.w_hi + a_lo.w_hi + a_hi.w_lo with fp32 accumulation (the lo.lo term, 2^-16 of a product, is dropped).
+// unchanged.  The activations stay fp32 in memory and LDS; lane group q takes the eight k values 4q .. 4q+3 and
+// 16+4q .. 16+4q+3 of the k-tile - chunks q and 4+q of its row, the conflict-free read pattern of the exact-fp32 loop
+// (chunks 2q, 2q+1 cost 20 % more LDS cycles in bank conflicts) - and the weight terms are stored in that k order inside
+// every k-tile.  It splits them the same way in registers and issues three 16x16x32 MFMAs per output fragment:
+// a_hi.w_hi + a_lo.w_hi + a_hi.w_lo with fp32 accumulation (the lo.lo term, 2^-16 of a product, is dropped).
 // One k-tile is then 12 bf16 MFMAs per 16 x 64 wave tile (192 cycles) instead of 32 exact-fp32 ones (1024 cycles).
 template <int FM>
 __device__ __forceinline__ void mma_tile_split(f32x4 (&acc)[FM][4], const char* sa, const char* sw, int arow0, int wrow0,
@@ -432,8 +434,8 @@ __device__ __forceinline__ void mma_tile_split(f32x4 (&acc)[FM][4], const char* 
     u32x4 a0[FM], a1[FM], wh[4], wl[4];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        a0[i] = *reinterpret_cast<const u32x4*>(sa + swz(arow0 + i * 16 + fr, 2 * fq));
-        a1[i] = *reinterpret_cast<const u32x4*>(sa + swz(arow0 + i * 16 + fr, 2 * fq + 1));
+        a0[i] = *reinterpret_cast<const u32x4*>(sa + swz(arow0 + i * 16 + fr, fq));
+        a1[i] = *reinterpret_cast<const u32x4*>(sa + swz(arow0 + i * 16 + fr, 4 + fq));
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -474,8 +476,8 @@ __device__ __forceinline__ void mma_tile_split3(f32x4 (&acc)[FM][4], const char*
     u32x4 a0[FM], a1[FM], wh[4], wm[4], wl[4];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        a0[i] = *reinterpret_cast<const u32x4*>(sa + swz(arow0 + i * 16 + fr, 2 * fq));
-        a1[i] = *reinterpret_cast<const u32x4*>(sa + swz(arow0 + i * 16 + fr, 2 * fq + 1));
+        a0[i] = *reinterpret_cast<const u32x4*>(sa + swz(arow0 + i * 16 + fr, fq));
+        a1[i] = *reinterpret_cast<const u32x4*>(sa + swz(arow0 + i * 16 + fr, 4 + fq));
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

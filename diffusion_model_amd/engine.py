@@ -288,6 +288,11 @@ class Engine:
         pw = PackedWeight(None, n, k, npad, kpad, b, geglu, conv_cin)
         if self.split_bf16:
             nkt = kpad // self.bk
+            # k order inside a k-tile: lane group q of the kernel holds k = 4q .. 4q+3 and 16+4q .. 16+4q+3 (its two
+            # conflict-free chunks of the fp32 activation row), so those eight terms sit together in the weight row
+            perm = torch.tensor([4 * q + e if e < 4 else 16 + 4 * q + e - 4 for q in range(4) for e in range(8)],
+                                device=wp.device)
+            wp = wp.view(npad, nkt, self.bk)[:, :, perm].reshape(npad, kpad)
             hi = wp.to(torch.bfloat16)
             r1 = wp - hi.float()
             if self.split_bf16 == 3:

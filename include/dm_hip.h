@@ -157,7 +157,8 @@ typedef struct DmGemmDesc {
      * 2: `w` is a two-term split-bf16 image - per packed row and k-tile of 32 values, 32 bf16 hi terms followed by 32
      *    bf16 lo terms (w ~ hi + lo, lo = bf16(w - hi)); same blocking and bytes as the fp32 image - and the launch
      *    forms a_hi w_hi + a_lo w_hi + a_hi w_lo on the bf16 MFMA with the fp32 activations split in registers (fp32
-     *    accumulation; error of a product ~2^-16 instead of 2^-24).
+     *    accumulation; error of a product ~2^-16 instead of 2^-24).  Inside a k-tile the terms are stored in the k
+     *    order 0-3, 16-19, 4-7, 20-23, 8-11, 24-27, 12-15, 28-31 (the eight values one lane group multiplies).
      * 3: three terms per operand (hi, mid, lo: 24 bits) and the six products down to 2^-16 of the leading one; what is
      *    dropped is 2^-24 of a product.  The image has two 128-byte rows per packed row and k-tile, stored
      *    [npad/64][kpad/32][2 planes][64 rows][128 B]: plane 0 = 32 hi | 32 mid terms, plane 1 = 32 lo terms | zeros. */
