@@ -3,6 +3,7 @@
 
     python bench.py                       # 1 GPU, config 2 (batch 1, 64x64 latent, fp32), K=3, W=1
     python bench.py --config 3            # batch 16, bf16
+    python bench.py --gpus N              # starts its own N ranks (one fresh process per GPU), or under a launcher:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -10,10 +11,16 @@ A "step" is one complete sampling pass: ``DDPMScheduler(num_train_timesteps=50).
 synthetic inputs (random-init deterministic weights, seeded context, device-side noise).  With N > 1
 every rank samples its own batch shard (weak scaling, no per-step communication) and the final latents
 are all-gathered over RCCL inside the timed region.  Rank 0 prints one JSON line.
+
+The default invocation (config 2, one GPU, no other flags) also runs two side measurements after the headline, each
+in a fresh child process, and reports them under ``secondary`` in the same line: config 3 (bf16, batch 16, CLIP
+context) and config 2 in the opt-in three-term split-bf16 product mode.  The headline fields are never taken from them.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -119,6 +126,88 @@ def pmc_traffic(config, batch, latent):
         return round(json.load(f)["per_launch"].get("conv3x3", 0.0)) or None
 
 
+def launch_ranks(n: int) -> int:
+    """``--gpus n`` outside a launcher: start n fresh child processes of this script, one rank per GPU, and return the
+    worst exit code.  This parent has made no GPU call (importing torch makes none); rank 0 inherits stdout, so its
+    JSON line is the job's; the other ranks' stdout goes to stderr."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    worst = 0
+    for pr in procs:
+        rc = pr.wait()
+        if rc != 0 and worst == 0:
+            worst = rc if rc > 0 else 128 - rc
+    return worst
+
+
+def run_stub(args) -> None:
+    """Plumbing rehearsal without a GPU (tests only; never a measurement): every rank "samples" its shard of a tiny
+    latent batch with torch on the CPU, then the real gather, barriers, max-over-ranks timing and JSON line run."""
+    rank, world, _ = init_distributed()
+    total = 2 * world + 1  # ragged on purpose
+    lo, hi = shard_bounds(total, world, rank)
+    full = torch.arange(total * 4 * 2 * 2, dtype=torch.float32).reshape(total, 4, 2, 2)
+
+    def one_step():
+        return gather_latents(full[lo:hi] * 2.0 + 1.0, total=total)
+
+    for _ in range(args.warmup):
+        one_step()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ok = bool(torch.equal(out, full * 2.0 + 1.0))
+    if rank == 0:
+        print(json.dumps({"metric": "stub (plumbing rehearsal, not a measurement)", "value": args.steps * total / elapsed,
+                          "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / args.steps * 1e3, "gather_ok": ok,
+                          "config": {"workload": "stub", "global_batch": total, "parallelism": f"dp{world}"}}))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if not ok:
+        sys.exit(1)
+    if os.environ.get("DM_BENCH_STUB_FAIL_RANK") == str(rank):  # lets a test see a rank's failure reach the launcher
+        sys.exit(3)
+
+
+def secondary_run(extra, timeout_s=280):
+    """One side measurement in a fresh child process (its own engine and arithmetic mode); returns the fields of its
+    JSON line that ``secondary`` reports, or {"error": ...}.  Never raises: the headline line must still be printed."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-secondary", *extra]
+    try:
+        t0 = time.perf_counter()
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        wall = time.perf_counter() - t0
+        line = next((l for l in reversed(res.stdout.splitlines()) if l.startswith("{")), None)
+        if res.returncode != 0 or line is None:
+            return {"error": f"exit code {res.returncode}", "stderr_tail": res.stderr[-400:]}
+        d = json.loads(line)
+        keep = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "kernel_classes", "setup_s")
+        out = {k: d[k] for k in keep if k in d}
+        out["command"] = "python bench.py " + " ".join(cmd[2:])
+        out["process_wall_s"] = round(wall, 1)
+        return out
+    except Exception as e:  # timeout, bad JSON, ...
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,7 +227,19 @@ def main():
                          "split-bf16 product modes (DM_FP32_SPLIT): 2 = two bf16 terms per operand, three products, about "
                          "16 bits of each operand (GEMM, conv and attention); 3 = three terms, six products, 24 bits "
                          "(GEMM and conv; attention exact fp32); the line's dtype field says which")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default invocation only: skip the config-3 and split-3 side measurements")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # CPU rehearsal of the multi-rank plumbing
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torchrun: this process becomes the launcher of its own ranks and touches no GPU itself
+        sys.exit(launch_ranks(args.gpus))
+    if args.stub:
+        return run_stub(args)
+    # the plain default invocation (what the round-end driver runs) also reports the side measurements
+    default_run = (args.gpus == 1 and args.config == 2 and not args.batch and not args.dtype and args.ddpm_steps == 50
+                   and args.sampler == "ddpm" and not args.fp32_split and not args.no_graph and not args.no_secondary
+                   and int(os.environ.get("WORLD_SIZE", "1")) == 1)
     if args.fp32_split:
         os.environ["DM_FP32_SPLIT"] = str(args.fp32_split)  # read when the engine is created
 
@@ -206,7 +307,7 @@ def main():
             return pixels
         context = clip(tokens).float() if clip is not None else ctx
         lat = sched.sample(model, shape, context, gen, device)
-        return gather_latents(lat) if world > 1 else lat
+        return gather_latents(lat, total=global_batch) if world > 1 else lat
 
     # set-up, outside warm-up and timing: weight packing and the per-shape GEMM tile/split autotune run on the
     # first forward of a process (like a compile step); a 2-step sampling call triggers both
@@ -289,6 +390,16 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(HW)
+        if default_run:
+            # side measurements under the same clock as the headline, each in a fresh process; they never replace a
+            # headline field.  config3 = the bf16 configuration the MFMA targets are quoted on; config2_split3 = this
+            # workload with every fp32 operand carried as three bf16 terms (24 bits, six products) - not the
+            # reference's arithmetic, reported for comparison only.
+            result["secondary"] = {
+                "config3": secondary_run(["--config", "3", "--steps", "3", "--warmup", "1"]),
+                "config2_split3": secondary_run(["--config", "2", "--fp32-split", "3", "--steps", str(args.steps),
+                                                 "--warmup", str(args.warmup)]),
+            }
         print(json.dumps(result))
     if world > 1:
         torch.distributed.barrier()

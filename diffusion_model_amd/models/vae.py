@@ -27,12 +27,20 @@ class VAEResidualBlock(nn.Module):
 
     def __init__(self, in_channels: int, out_channels: int):
         super().__init__()
-        self.groupnorm_1 = nn.GroupNorm(32, in_channels)
-        self.conv_1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1)
-        self.groupnorm_2 = nn.GroupNorm(32, out_channels)
-        self.conv_2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1)
+        # parameter names of the reference's ResidualBlock (src/models/blocks.py:32-42), so that a state_dict of the
+        # reference's Encoder loads into this one; its linear_time (the time projection its Encoder can never feed)
+        # has no counterpart here and is dropped on load
+        self.groupnorm_feature = nn.GroupNorm(32, in_channels)
+        self.conv_feature = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1)
+        self.groupnorm_merged = nn.GroupNorm(32, out_channels)
+        self.conv_merged = nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1)
         self.residual_layer = (nn.Identity() if in_channels == out_channels
                                else nn.Conv2d(in_channels, out_channels, kernel_size=1, padding=0))
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for k in [k for k in state_dict if k.startswith(prefix + "linear_time.")]:
+            state_dict.pop(k)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return _run_single(self, x)
@@ -45,6 +53,15 @@ class VAEAttentionBlock(nn.Module):
         super().__init__()
         self.groupnorm = nn.GroupNorm(32, channels)
         self.attention = SelfAttention(1, channels)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # the reference's block holds an nn.MultiheadAttention (src/models/encoder.py:36-40), whose fused input
+        # projection is a bare parameter pair: attention.in_proj_weight / in_proj_bias
+        for old, new in (("attention.in_proj_weight", "attention.in_proj.weight"),
+                         ("attention.in_proj_bias", "attention.in_proj.bias")):
+            if prefix + old in state_dict:
+                state_dict[prefix + new] = state_dict.pop(prefix + old)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return _run_single(self, x)

@@ -8,7 +8,7 @@ in the tests).  The reference has no distributed code; this is the build's own m
 from __future__ import annotations
 
 import os
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -47,25 +47,35 @@ def shard_batch(t: torch.Tensor, world: int = None, rank: int = None) -> torch.T
     return t[a:b]
 
 
-def gather_latents(local: torch.Tensor) -> torch.Tensor:
-    """All ranks' latents concatenated along the batch in rank order (shards may differ in size)."""
+def gather_latents(local: torch.Tensor, total: Optional[int] = None) -> torch.Tensor:
+    """All ranks' latents concatenated along the batch in rank order: ONE collective, no host synchronisation.
+
+    ``total`` is the job's image count when the shards came from ``shard_bounds(total, world, rank)`` and may differ
+    in size by one; every rank derives every shard's size from that same function, so nothing has to be exchanged
+    first.  ``None`` means equal shards (``world * local.shape[0]`` images).  A ragged job pads each shard to the
+    largest one for the collective and drops the padding afterwards.
+    """
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
     local = local.contiguous()
-    sizes = [torch.zeros(1, dtype=torch.long, device=local.device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.long, device=local.device))
-    counts: List[int] = [int(s.item()) for s in sizes]
-    if len(set(counts)) == 1:
-        out = torch.empty((world * counts[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    n = local.shape[0]
+    if total is None:
+        total = world * n
+    counts: List[int] = [b - a for a, b in (shard_bounds(total, world, r) for r in range(world))]
+    if counts[rank] != n:
+        raise ValueError(f"rank {rank} holds {n} images but shard_bounds({total}, {world}, {rank}) gives {counts[rank]}")
+    tail = tuple(local.shape[1:])
+    pad = max(counts)
+    if pad == min(counts):
+        out = torch.empty((total,) + tail, dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local)
         return out
-    bufs = [torch.empty((c,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device) for c in counts]
-    pad = max(counts)
-    padded = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    padded[: local.shape[0]] = local
-    recv = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(recv, padded)
-    for i, c in enumerate(counts):
-        bufs[i] = recv[i][:c]
-    return torch.cat(bufs, 0)
+    send = local
+    if n < pad:
+        send = torch.zeros((pad,) + tail, dtype=local.dtype, device=local.device)
+        send[:n] = local
+    recv = torch.empty((world * pad,) + tail, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(recv, send)
+    recv = recv.view((world, pad) + tail)
+    return torch.cat([recv[r, :c] for r, c in enumerate(counts)], 0)

@@ -10,6 +10,8 @@ along the batch, so the model sees a doubled batch and the two halves are recomb
 """
 from typing import Optional, Tuple
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -105,7 +107,7 @@ def _denoise_graph(model, sampler, context, latents, cfg_scale, do_cfg):
     eng, _ = model.hip_pack(latents.device)
     key = (id(model), id(eng), shape, str(latents.device), context.shape[1], type(sampler).__name__, getattr(sampler, "lms_order", 0), first, n,
            tuple(float(t) for t in sampler.timesteps), float(cfg_scale), bool(do_cfg))
-    cache = sampler.__dict__.setdefault("_dm_loops", {})
+    cache = _LOOPS.setdefault(sampler, {})
     loop = cache.get(key)
     if loop is None:
         cache.clear()
@@ -125,6 +127,12 @@ def _denoise_graph(model, sampler, context, latents, cfg_scale, do_cfg):
 
 class _GraphSwitch:
     use_hip_graph = True
+
+
+# Captured K-sampler loops, keyed by the sampler object WITHOUT living in it: a loop holds device buffers, the model's
+# packed weights, a stream and a ctypes graph handle, none of which may ride along when a caller copies or pickles its
+# sampler.  The entry goes away with the sampler.
+_LOOPS = weakref.WeakKeyDictionary()
 
 
 @torch.no_grad()

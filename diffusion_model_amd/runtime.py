@@ -411,13 +411,13 @@ def run_clip(eng: Engine, pk: NS, tokens: torch.Tensor):
 # VAE decoder / encoder (this build's own design - the reference has no runnable autoencoder; see models/vae.py)
 # ----------------------------------------------------------------------------------------------
 def pack_vae_residual(m, eng: Engine) -> NS:
-    cin, cout = m.conv_1.in_channels, m.conv_1.out_channels
+    cin, cout = m.conv_feature.in_channels, m.conv_feature.out_channels
     fold = (eng.fuse_skip and isinstance(m.residual_layer, torch.nn.Conv2d) and cin % eng.bk == 0 and cout % eng.bk == 0)
     return NS(kind="vres", cin=cin, cout=cout,
-              gn1_w=_f32(eng, m.groupnorm_1.weight), gn1_b=_f32(eng, m.groupnorm_1.bias), gn1_eps=m.groupnorm_1.eps,
-              conv1=eng.pack_conv3x3(m.conv_1),
-              gn2_w=_f32(eng, m.groupnorm_2.weight), gn2_b=_f32(eng, m.groupnorm_2.bias), gn2_eps=m.groupnorm_2.eps,
-              conv2=eng.pack_conv3x3(m.conv_2, skip=m.residual_layer if fold else None),
+              gn1_w=_f32(eng, m.groupnorm_feature.weight), gn1_b=_f32(eng, m.groupnorm_feature.bias), gn1_eps=m.groupnorm_feature.eps,
+              conv1=eng.pack_conv3x3(m.conv_feature),
+              gn2_w=_f32(eng, m.groupnorm_merged.weight), gn2_b=_f32(eng, m.groupnorm_merged.bias), gn2_eps=m.groupnorm_merged.eps,
+              conv2=eng.pack_conv3x3(m.conv_merged, skip=m.residual_layer if fold else None),
               res=None if (fold or isinstance(m.residual_layer, torch.nn.Identity)) else eng.pack_conv1x1(m.residual_layer),
               fold_skip=fold)
 
@@ -463,10 +463,15 @@ def pack_vae_layers(layers, eng: Engine) -> List[NS]:
                 conv = m
                 npd = _rup(cout, 8) if cout > 4 else 4
                 if npd != cout:  # zero output rows keep the padded columns exactly zero (bias included)
-                    conv = torch.nn.Conv2d(cin, npd, 3, stride=m.stride, padding=1).to(m.weight.device, m.weight.dtype)
+                    # a parameter holder built without initialisation: the pack path must not draw from the global RNG
+                    conv = torch.nn.utils.skip_init(torch.nn.Conv2d, cin, npd, 3, stride=m.stride, padding=1,
+                                                    device=m.weight.device, dtype=m.weight.dtype)
                     with torch.no_grad():
                         conv.weight.copy_(_pad_rows(m.weight.detach(), npd))
-                        conv.bias.copy_(_pad_rows(m.bias.detach(), npd) if m.bias is not None else torch.zeros(npd))
+                        if m.bias is not None:
+                            conv.bias.copy_(_pad_rows(m.bias.detach(), npd))
+                        else:
+                            conv.bias.zero_()
                 asym = m.stride == (2, 2) and m.padding == (0, 0)
                 if not asym and m.padding != (1, 1):
                     raise RuntimeError("VAE convolutions are 3x3 with padding 1, or stride 2 with the (0,1,0,1) padding")

@@ -23,6 +23,7 @@ class DDPMScheduler(BaseScheduler):
                          beta_schedule=beta_schedule, device=device)
         self.clip_sample = clip_sample
         self.use_hip_graph = True
+        self.max_resident_loops = 4
         self._coef_host = None
         self._coef_dev = {}
         self._loops = {}
@@ -76,12 +77,14 @@ class DDPMScheduler(BaseScheduler):
         if device.type != "cuda":
             raise RuntimeError("DDPMScheduler.sample: device must be the HIP device ('cuda'); there is no CPU path")
         T = self.num_train_timesteps
+        from ..models.diffusion import Diffusion
+        if isinstance(model, Diffusion) and context is not None:
+            # the loop state draws x_T and the T-1 noises itself, in the reference's order, straight into its buffers
+            st = self._loop_state(model, tuple(shape), device, context.shape[1])
+            return st.run(self, model, None, None, context, None, generator=generator)
         # generator consumption order of the reference: x_T, then one draw per step with t > 0
         x_T = draw_normal(shape, generator, device)
         noises = [draw_normal(shape, generator, device) for _ in range(T - 1)]
-        from ..models.diffusion import Diffusion
-        if isinstance(model, Diffusion) and context is not None:
-            return self.sample_from_noise(model, x_T, noises, context)
         sample = x_T
         for i, t in enumerate(reversed(range(T))):
             timestep = torch.full((shape[0],), t, device=device, dtype=torch.long)
@@ -114,8 +117,13 @@ class DDPMScheduler(BaseScheduler):
         eng, _ = model.hip_pack(device)
         key = (id(model), shape, str(device), id(eng), sk)
         st = self._loops.get(key)
+        if st is not None:
+            self._loops[key] = self._loops.pop(key)  # most recently used last
         if st is None:
-            self._loops.clear()  # one resident loop state at a time
+            # a few resident loop states (captured graph + buffers each), least recently used dropped first: a caller
+            # that alternates between two shapes or models does not re-capture on every call
+            while len(self._loops) >= self.max_resident_loops:
+                self._loops.pop(next(iter(self._loops)))
             T = self.num_train_timesteps
             st = StepLoop(model, shape, device, sk, timesteps=list(range(T - 1, -1, -1)),
                           coef=self.step_coefficients().flip(0), step="dm_ddpm_step", clip=self.clip_sample,
@@ -233,7 +241,20 @@ class StepLoop:
         finally:
             eng.arena.frozen = False
 
-    def run(self, sched, model, x_T, noises, context, trace):
+    def _draw(self, generator):
+        """x_T, then one draw per noisy step - the reference's generator order (ddpm_scheduler.py:187,136) - written
+        straight into the loop's buffers when the generator lives on this device (no staging tensors, no copies)."""
+        if generator is None or generator.device.type == self.device.type:
+            torch.randn(self.shape, generator=generator, out=self.x)
+            for i in range(self.n_noise):
+                torch.randn(self.shape, generator=generator, out=self.noise[i])
+        else:  # a CPU generator (reproducible comparisons): draw there, call by call, and copy
+            self.x.copy_(draw_normal(self.shape, generator, self.device))
+            for i in range(self.n_noise):
+                self.noise[i].copy_(draw_normal(self.shape, generator, self.device))
+
+    def run(self, sched, model, x_T, noises, context, trace, generator=None):
+        """``x_T`` / ``noises`` given: explicit draws; both None: drawn here from ``generator``."""
         if rt._signature(model) != self.sig:  # parameters changed: repack and drop the stale graph
             self.eng, self.pk = model.hip_pack(self.device)
             self.sig = rt._signature(model)
@@ -245,11 +266,14 @@ class StepLoop:
         caller = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(caller)
         with torch.cuda.stream(self.stream):
-            self.x.copy_(x_T.to(torch.float32))
-            if len(noises) != self.n_noise:
-                raise RuntimeError(f"expected {self.n_noise} noise tensors, got {len(noises)}")
-            for i, nz in enumerate(noises):
-                self.noise[i].copy_(nz)
+            if x_T is None:
+                self._draw(generator)
+            else:
+                self.x.copy_(x_T.to(torch.float32))
+                if len(noises) != self.n_noise:
+                    raise RuntimeError(f"expected {self.n_noise} noise tensors, got {len(noises)}")
+                for i, nz in enumerate(noises):
+                    self.noise[i].copy_(nz)
             self.counter.zero_()
             self.eng.reset()
             if self.tproj_table is None:

@@ -55,10 +55,10 @@ def _entry_shapes(e) -> List[Tuple[str, Tuple[int, ...]]]:
                [("weight", (c, c, 3, 3)), ("bias", (c,))]
     if kind == "res":
         _, cin, cout = e
-        s = [("groupnorm_1.weight", (cin,)), ("groupnorm_1.bias", (cin,)),
-             ("conv_1.weight", (cout, cin, 3, 3)), ("conv_1.bias", (cout,)),
-             ("groupnorm_2.weight", (cout,)), ("groupnorm_2.bias", (cout,)),
-             ("conv_2.weight", (cout, cout, 3, 3)), ("conv_2.bias", (cout,))]
+        s = [("groupnorm_feature.weight", (cin,)), ("groupnorm_feature.bias", (cin,)),
+             ("conv_feature.weight", (cout, cin, 3, 3)), ("conv_feature.bias", (cout,)),
+             ("groupnorm_merged.weight", (cout,)), ("groupnorm_merged.bias", (cout,)),
+             ("conv_merged.weight", (cout, cout, 3, 3)), ("conv_merged.bias", (cout,))]
         if cin != cout:
             s += [("residual_layer.weight", (cout, cin, 1, 1)), ("residual_layer.bias", (cout,))]
         return s
@@ -93,10 +93,10 @@ def _sub(state: State, prefix: str) -> State:
 
 
 def residual_block(w: State, x: torch.Tensor) -> torch.Tensor:
-    h = F.group_norm(x, 32, w["groupnorm_1.weight"], w["groupnorm_1.bias"], eps=1e-5)
-    h = F.conv2d(F.silu(h), w["conv_1.weight"], w["conv_1.bias"], padding=1)
-    h = F.group_norm(h, 32, w["groupnorm_2.weight"], w["groupnorm_2.bias"], eps=1e-5)
-    h = F.conv2d(F.silu(h), w["conv_2.weight"], w["conv_2.bias"], padding=1)
+    h = F.group_norm(x, 32, w["groupnorm_feature.weight"], w["groupnorm_feature.bias"], eps=1e-5)
+    h = F.conv2d(F.silu(h), w["conv_feature.weight"], w["conv_feature.bias"], padding=1)
+    h = F.group_norm(h, 32, w["groupnorm_merged.weight"], w["groupnorm_merged.bias"], eps=1e-5)
+    h = F.conv2d(F.silu(h), w["conv_merged.weight"], w["conv_merged.bias"], padding=1)
     if "residual_layer.weight" in w:
         x = F.conv2d(x, w["residual_layer.weight"], w["residual_layer.bias"])
     return h + x

@@ -35,7 +35,7 @@ def _worker(rank, world, port, total, out):
     full = torch.arange(total * 4 * 2 * 2, dtype=torch.float32).reshape(total, 4, 2, 2)
     mine = shard_batch(full)                       # this rank's images
     latents = mine * 2.0 + 1.0                     # stands in for the sampled latents of the shard
-    gathered = gather_latents(latents)
+    gathered = gather_latents(latents, total=total)
     ok = torch.equal(gathered, full * 2.0 + 1.0)
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -58,3 +58,34 @@ def test_gather_equal_shards_gloo(tmp_path):
 
 def test_gather_unequal_shards_gloo(tmp_path):
     _run(5, tmp_path)
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` outside a launcher becomes the launcher: two fresh rank processes (gloo here, a
+    stub workload on the CPU), one JSON line from rank 0 saying n_gpus = 2, exit code 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["DM_DIST_BACKEND"] = "gloo"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub", "--steps", "2",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=240, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["gather_ok"] is True
+    assert out["config"]["parallelism"] == "dp2"
+
+
+def test_bench_rank_failure_is_reported():
+    """A rank that exits non-zero makes the launcher exit non-zero, whatever rank 0 printed."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(DM_DIST_BACKEND="gloo", DM_BENCH_STUB_FAIL_RANK="1")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub", "--steps", "1",
+                          "--warmup", "0"], capture_output=True, text=True, timeout=240, env=env)
+    assert res.returncode == 3, (res.returncode, res.stderr[-1000:])
