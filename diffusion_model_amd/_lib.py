@@ -28,7 +28,12 @@ TILE_E128x128, TILE_E128x64, TILE_E64x64, TILE_E64x128 = 24, 25, 26, 27  # early
 TILE_DIMS.update({TILE_E128x128: (128, 128), TILE_E128x64: (128, 64), TILE_E64x64: (64, 64), TILE_E64x128: (64, 128)})
 TILE_DIMS.update({TILE_D256x64_S2: (256, 64), TILE_D128x64_S2: (128, 64), TILE_D64x64_S2: (64, 64),
                   TILE_D256x256_S2: (256, 256)})
-ALL_TILES = tuple(TILE_DIMS)
+ALL_TILES = tuple(TILE_DIMS)  # tiles every dense / conv problem may use
+# row-panel tiles (bf16, dense, K = 320 / 640): a block owns `bm` rows and all column tiles; DmGemmDesc.splitk counts
+# column slices for them
+TILE_P64, TILE_P128 = 31, 32
+PANEL_TILES = {TILE_P64: 64, TILE_P128: 128}
+TILE_DIMS.update({TILE_P64: (64, 64), TILE_P128: (128, 64)})
 
 _ERR = {1: "invalid argument / unsupported shape", 2: "HIP launch error", 3: "misaligned pointer or stride",
         4: "unsupported attention head dimension (kernels exist for 40, 64, 80 and 160; wider heads go through the GEMM route)",
@@ -71,6 +76,7 @@ _PROTOS = {
     "dm_gemm_workspace_bytes": (C.c_long, [_i, _i, _i]),
     "dm_gemm_streamk_workspace_bytes": (C.c_long, [_i, _i, _i, _i]),
     "dm_gemm_stats_supported": (C.c_int, [_i, _i, _i]),
+    "dm_gemm_panel_supported": (C.c_int, [C.POINTER(GemmDesc), _i, _i]),
     "dm_gemm_gn_supported": (C.c_int, [_i, _i, _i, _i, _i, _i, _i]),
     "dm_groupnorm_apply_sums": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _f, _i, _vp]),
     "dm_zero": (C.c_int, [_vp, _l, _vp]),
@@ -135,7 +141,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dm_abi_version() != 9:
+        if handle.dm_abi_version() != 10:
             raise RuntimeError("libdm_hip.so ABI version mismatch; rebuild with `python build.py`")
         _lib = handle
     return _lib

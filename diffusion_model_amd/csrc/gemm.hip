@@ -30,6 +30,7 @@
 // (GEGLU: 8 value columns and their 8 gates).
 #include "common.h"
 #include "dm_hip.h"
+#include "panel.h"
 
 namespace {
 
@@ -2082,8 +2083,13 @@ long streamk_counter_bytes(int tile, int M, int N) {
 }
 }  // namespace
 
+extern "C" int dm_gemm_panel_supported(const DmGemmDesc* d, int tile, int nsplit) {
+    return d ? dm_panel_supported(d, tile, nsplit) : 0;
+}
+
 extern "C" int dm_gemm_stats_supported(int tile, int rows_per_batch, int splitk) {
     int bm, bn;
+    if (const int pr = dm_panel_rows(tile)) return rows_per_batch > 0 && rows_per_batch % (pr / 4) == 0;  // splitk = column slices
     if (tile_dims(tile, &bm, &bn) || rows_per_batch <= 0 || splitk > 1) return 0;
     return rows_per_batch % tile_wave_rows(tile) == 0;
 }
@@ -2149,6 +2155,13 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
 
     int tile = d->tile, splitk = d->splitk;
     if (tile == DM_TILE_AUTO) dm_gemm_plan(d->dtype, d->m, d->n, d->k, d->epi, &tile, &splitk);
+    if (dm_panel_rows(tile)) {
+        // row-panel form: `splitk` counts column slices; its own shape rules (panel.hip)
+        if (d->ln_in && (!d->ln_colsum || !dm_aligned16(d->ln_colsum) || (reinterpret_cast<uintptr_t>(d->ln_in) & 7u)))
+            return DM_ERR_ARG;
+        if (d->ln_out && (d->epi != DM_EPI_PLAIN || (reinterpret_cast<uintptr_t>(d->ln_out) & 7u))) return DM_ERR_ARG;
+        return dm_panel_launch(d, tile, splitk < 1 ? 1 : splitk, stream);
+    }
     int bm, bn;
     if (tile_dims(tile, &bm, &bn)) return DM_ERR_ARG;
     if (d->a2 && tile < DM_TILE_D128x128_S2) return DM_ERR_ARG;  // only the direct-to-LDS loop reads a second operand

@@ -459,7 +459,7 @@ class Engine:
         tile, sk = C.c_int(0), C.c_int(1)
         if self.tile_override is not None:
             tile.value, sk.value = self.tile_override
-            if d.epi != _lib.EPI_PLAIN and sk.value > 1:
+            if d.epi != _lib.EPI_PLAIN and sk.value > 1 and tile.value not in _lib.PANEL_TILES:
                 sk.value = 1
         else:
             no_legacy = ln_in is not None or ln_out
@@ -480,7 +480,8 @@ class Engine:
                 tile.value, sk.value = best
             else:
                 self.lib.dm_gemm_plan(self.dm, m, pw.n, pw.k, d.epi, C.byref(tile), C.byref(sk))
-        if (ln_in is not None or ln_out) and sk.value > 1:
+        panel = tile.value in _lib.PANEL_TILES  # row-panel form: sk counts column slices, no workspace
+        if (ln_in is not None or ln_out) and sk.value > 1 and not panel:
             sk.value = 1  # the separate split-K reduction launch does not carry the LayerNorm epilogue
         d.tile, d.splitk = tile.value, sk.value
         if gn_rec is not None:
@@ -505,7 +506,7 @@ class Engine:
             st = self._stats_alloc(m, 1).view(m, 2)
             self._ln_stats[out.data_ptr()] = st
             d.ln_out = st.data_ptr()
-        if sk.value > 1:
+        if sk.value > 1 and not panel:
             self._bind_workspace(d, m, pw.n, sk.value)
         elif sk.value < 0:
             self._bind_streamk(d, tile.value, m, pw.n, -sk.value)
@@ -569,6 +570,7 @@ class Engine:
     _TUNE_SK = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)
     _TUNE_STREAMK = (256, 512, 768, 1024)  # blocks sharing the (tile, k-tile) work list
     _TUNE_STREAMK_MULT = (2, 3, 4, 6, 8, 12, 16, 24)  # ... and whole multiples of the tile count
+    _TUNE_PANEL_SLICES = (1, 2, 3, 4, 5, 8, 10, 16, 20)  # column slices (grid.y) of the row-panel tiles
     _TUNE_LEGACY_SK = False  # split-K with a separate reduction launch: measured slower overall than the work-list
                              # form once GroupNorm / LayerNorm statistics ride in the GEMM epilogue
 
@@ -607,6 +609,8 @@ class Engine:
 
     def _bind_choice(self, d: GemmDesc, tile: int, sk: int):
         d.tile, d.splitk = tile, sk
+        if tile in _lib.PANEL_TILES:
+            return
         if sk > 1:
             self._bind_workspace(d, d.m, d.n, sk)
         elif sk < 0:
@@ -656,6 +660,22 @@ class Engine:
                     seen.append((t, (tile, -grid)))
                 if t is not None and t < best_t:
                     best, best_t = (tile, -grid), t
+        # row-panel form (bf16, K = 320 / 640): a block keeps its rows in registers and walks all column tiles, or the
+        # slice of them that one of `ns` column slices holds
+        d.workspace, d.workspace_bytes = None, 0
+        for tile, bm in _lib.PANEL_TILES.items():
+            panels = (d.m + bm - 1) // bm
+            for ns in self._TUNE_PANEL_SLICES:
+                if ns > 1 and panels * ns > 4096:
+                    break
+                if not self.lib.dm_gemm_panel_supported(C.byref(d), tile, ns):
+                    continue
+                d.tile, d.splitk = tile, ns
+                t = self._time_candidate(d)
+                if t is not None:
+                    seen.append((t, (tile, ns)))
+                if t is not None and t < best_t:
+                    best, best_t = (tile, ns), t
         # The sweep times every candidate once; candidates within a few percent of each other change places from run to
         # run.  The three fastest are timed again, interleaved, three more times each, and the smallest median wins.
         # A work list whose block count is a whole multiple of the tile count cuts every tile at the same k positions, so
@@ -666,6 +686,8 @@ class Engine:
         # within 3 % of the fastest.
         def aligned(c):
             tile, sk = c
+            if tile in _lib.PANEL_TILES:
+                return False
             bm, bn = _lib.TILE_DIMS[tile]
             tiles = ((d.m + bm - 1) // bm) * ((d.n + bn - 1) // bn)
             return sk == 1 or (sk < 0 and (-sk) % tiles == 0)

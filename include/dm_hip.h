@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 9
+#define DM_ABI_VERSION 10
 
 #define DM_F32 0
 #define DM_BF16 1
@@ -65,6 +65,13 @@ extern "C" {
 #define DM_TILE_E128x64 25
 #define DM_TILE_E64x64 26
 #define DM_TILE_E64x128 27
+/* P: row-panel form for short contractions (bf16, dense, K = 320 or 640, N a multiple of 64, plain or GEGLU
+ * epilogue): a block owns 64 / 128 rows, keeps them in registers for the whole launch and walks ALL column
+ * tiles of 64 (weights streamed through an LDS ring by a loader wave), so the activations are fetched once and the
+ * row sums of a following LayerNorm need no atomics.  For these tiles `splitk` (>= 1) is the number of column slices
+ * the column tiles are dealt to (grid.y), not a split of k; no workspace.  P128 exists for K = 320 only. */
+#define DM_TILE_P64 31
+#define DM_TILE_P128 32
 
 int dm_abi_version(void);
 
@@ -174,6 +181,8 @@ long dm_gemm_workspace_bytes(int m, int n, int splitk);
  * workspace. */
 long dm_gemm_streamk_workspace_bytes(int tile, int m, int n, int blocks);
 int dm_gemm_stats_supported(int tile, int rows_per_batch, int splitk);
+/* 1 when the descriptor's problem can run on the row-panel tile `tile` (DM_TILE_P*) with `nsplit` column slices. */
+int dm_gemm_panel_supported(const DmGemmDesc* d, int tile, int nsplit);
 /* 1 when DmGemmDesc.gn_sums may be used with this tile: C = channels that are normalised (see above). */
 int dm_gemm_gn_supported(int dtype, int tile, int conv, int c, int groups, int rows_per_batch, int splitk);
 /* order[p] = source weight row of packed row p (or -1 for a zero row), for p in [0, npad). */

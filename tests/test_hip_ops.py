@@ -638,3 +638,123 @@ def test_wide_tile_is_refused_where_unsupported(dev):
                 eng.gemm(torch.zeros(2 * 64, 64, device=dev, dtype=dt), pw,
                          conv=dict(batch=2, hin=8, win=8, hout=4, wout=4, stride=2, cin_real=64))
         eng.tile_override = None
+
+
+# ------------------------------------------------------------------------------------------- row-panel GEMM (bf16)
+PANEL = tuple(_lib.PANEL_TILES)
+
+
+def _bf16_engine(dev):
+    e = Engine.get(dev, torch.bfloat16)
+    e.reset()
+    e.tile_override = None
+    return e
+
+
+@pytest.mark.parametrize("m,n,k", [(200, 320, 320), (1000, 960, 320), (260, 640, 640), (512, 1920, 640), (64, 64, 320)])
+@pytest.mark.parametrize("tile", PANEL)
+@pytest.mark.parametrize("ns", [1, 2, 5])
+def test_gemm_panel_dense(dev, m, n, k, tile, ns):
+    """Row-panel tiles (A rows stationary in registers, all column tiles per block, `ns` column slices): plain epilogue with
+    bias and residual, ragged last row panel, strided operands."""
+    eng = _bf16_engine(dev)
+    if tile == _lib.TILE_P128 and k != 320:
+        pytest.skip("P128 exists for K = 320")
+    if ns > n // 64:
+        pytest.skip("more column slices than column tiles")
+    a = tin("pn.a", (m, k)); w = tin("pn.w", (n, k), scale=1 / math.sqrt(k)); b = tin("pn.b", (n,)); r = tin("pn.r", (m, n))
+    lin = torch.nn.Linear(k, n)
+    with torch.no_grad():
+        lin.weight.copy_(w); lin.bias.copy_(b)
+    pw = eng.pack_linear(lin)
+    abuf = torch.zeros(m, k + 64, dtype=eng.dtype, device=dev); abuf[:, 32:32 + k] = up(eng, a)
+    cbuf = torch.zeros(m, n + 128, dtype=eng.dtype, device=dev)
+    rbuf = torch.zeros(m, n + 32, dtype=eng.dtype, device=dev); rbuf[:, 32:] = up(eng, r)
+    eng.tile_override = (tile, ns)
+    try:
+        eng.gemm(abuf[:, 32:32 + k], pw, out=cbuf[:, 64:64 + n], residual=rbuf[:, 32:])
+    finally:
+        eng.tile_override = None
+    ref = rnd(a, eng.dtype) @ rnd(w, eng.dtype).t() + b + rnd(r, eng.dtype)
+    assert max_rel(cbuf[:, 64:64 + n].float(), ref) < BF16_TOL
+    assert float(cbuf[:, :64].abs().max()) == 0.0 and float(cbuf[:, 64 + n:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("geglu", [False, True])
+@pytest.mark.parametrize("tile", PANEL)
+@pytest.mark.parametrize("ns", [1, 3])
+@pytest.mark.parametrize("c", [320, 640])
+def test_gemm_panel_folded_layernorm(dev, geglu, tile, ns, c):
+    """The LayerNorm fold on the panel tiles: the producer's row sums come out of registers (one plain store per row
+    when a block owns whole rows, atomics when the columns are sliced), the consumer applies mean / rstd."""
+    eng = _bf16_engine(dev)
+    if tile == _lib.TILE_P128 and c != 320:
+        pytest.skip("P128 exists for K = 320")
+    m, k0 = 300, c
+    n = 8 * c if geglu else 3 * c
+    a = tin("pl.a", (m, k0)); w0 = tin("pl.w0", (c, k0), scale=1 / math.sqrt(k0)); b0 = tin("pl.b0", (c,)) + 0.7
+    r = tin("pl.r", (m, c)) * 2
+    gamma = tin("pl.g", (c,)) + 1; beta = tin("pl.be", (c,))
+    w1 = tin("pl.w1", (n, c), scale=1 / math.sqrt(c)); b1 = tin("pl.b1", (n,))
+    l0 = torch.nn.Linear(k0, c); l1 = torch.nn.Linear(c, n); ln = torch.nn.LayerNorm(c, eps=1e-5)
+    with torch.no_grad():
+        l0.weight.copy_(w0); l0.bias.copy_(b0); l1.weight.copy_(w1); l1.bias.copy_(b1)
+        ln.weight.copy_(gamma); ln.bias.copy_(beta)
+    p0 = eng.pack_linear(l0); p1 = eng.pack_linear(l1, geglu=geglu, ln=ln)
+    eng.tile_override = (tile, ns)
+    try:
+        t = eng.gemm(up(eng, a), p0, residual=up(eng, r), ln_out=True)
+        sums = eng.ln_stats(t).clone()
+        out = eng.gemm(t, p1, ln_in=eng.ln_stats(t))
+    finally:
+        eng.tile_override = None
+    tt = rnd(rnd(a, eng.dtype) @ rnd(w0, eng.dtype).t() + b0 + rnd(r, eng.dtype), eng.dtype)
+    assert max_rel(t.float(), tt) < BF16_TOL
+    # the row sums are those of the values as stored
+    ts = t.float().cpu().double()
+    assert max_rel(sums[:, 0].cpu(), ts.sum(1)) < 1e-5 and max_rel(sums[:, 1].cpu(), (ts * ts).sum(1)) < 1e-5
+    y = F.linear(F.layer_norm(tt, (c,), gamma, beta, 1e-5), w1, b1)
+    if geglu:
+        v, g = y.chunk(2, dim=-1)
+        y = v * F.gelu(g)
+    assert max_rel(out.float(), y) < 3e-2
+
+
+@pytest.mark.parametrize("tile", PANEL)
+@pytest.mark.parametrize("ns", [1, 2])
+def test_gemm_panel_groupnorm_statistics(dev, tile, ns):
+    """Per-channel sums of the stored output accumulated by the panel tiles feed the GroupNorm that follows."""
+    eng = _bf16_engine(dev)
+    batch, hw, c = 3, 256, 320
+    m = batch * hw
+    a = tin("ps.a", (m, c)); w = tin("ps.w", (c, c), scale=1 / math.sqrt(c)); b = tin("ps.b", (c,))
+    gamma = tin("ps.g", (c,)) + 1; beta = tin("ps.be", (c,))
+    conv = torch.nn.Conv2d(c, c, 1)
+    with torch.no_grad():
+        conv.weight.copy_(w.reshape(c, c, 1, 1)); conv.bias.copy_(b)
+    pw = eng.pack_conv1x1(conv)
+    eng.tile_override = (tile, ns)
+    try:
+        t = eng.gemm(up(eng, a), pw, gn_batch=batch)
+        assert eng._gn_lookup(t, batch) is not None  # the statistics were accumulated by the launch
+        y = eng.groupnorm(t, batch, hw, gamma.to(dev), beta.to(dev), 1e-5, silu=True)
+    finally:
+        eng.tile_override = None
+    tt = t.float().cpu()
+    ref = F.silu(F.group_norm(tt.reshape(batch, hw, c).permute(0, 2, 1), 32, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(m, c)
+    assert max_rel(y.float(), ref) < BF16_TOL
+
+
+def test_gemm_panel_refused_where_unsupported(dev):
+    """The panel tiles exist for bf16, dense, K = 320 / 640 and N a multiple of 64; everything else is DM_ERR_ARG."""
+    for dt, k, n in ((torch.float32, 320, 320), (torch.bfloat16, 256, 320), (torch.bfloat16, 320, 96)):
+        eng = Engine.get(dev, dt)
+        eng.reset()
+        lin = torch.nn.Linear(k, n)
+        pw = eng.pack_linear(lin)
+        eng.tile_override = (_lib.TILE_P128, 1)
+        try:
+            with pytest.raises(RuntimeError):
+                eng.gemm(torch.zeros(128, k, dtype=dt, device=dev), pw)
+        finally:
+            eng.tile_override = None

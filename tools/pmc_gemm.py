@@ -24,7 +24,7 @@ if sys.argv[4] == "conv":
     geom = dict(batch=b, hin=hw, win=hw, hout=hw, wout=hw, cin_real=cin)
 else:
     m, n, k = (int(v) for v in sys.argv[4:7])
-    pw = eng.pack_linear(torch.nn.Linear(k, n).to(dev))
+    pw = eng.pack_linear(torch.nn.Linear(k, n).to(dev), geglu="geglu" in sys.argv[7:])  # trailing "geglu": GEGLU epilogue
     a = torch.randn(m, k, device=dev).to(dt)
     geom = None
 out = None
