@@ -58,7 +58,8 @@ class GemmDesc(C.Structure):
         ("tile", C.c_int),
         ("splitk", C.c_int),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_long),
-        ("stats", C.c_void_p), ("ld_stats", C.c_long),
+        ("stats", C.c_void_p), ("ld_stats", C.c_long), ("stats_cpg", C.c_int), ("stats_ch0", C.c_int),
+        ("stats2", C.c_void_p), ("ld_stats2", C.c_long), ("stats2_cpg", C.c_int), ("stats2_ch0", C.c_int),
         ("ln_in", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_out", C.c_void_p),
         ("a2", C.c_void_p), ("lda2", C.c_long), ("cin2", C.c_int),
         ("pad_hi_only", C.c_int),

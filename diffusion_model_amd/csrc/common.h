@@ -144,6 +144,49 @@ __device__ __forceinline__ f32x2 gelu_erf_fast_f2(f32x2 x) {
     return __builtin_elementwise_fma(__builtin_elementwise_abs(h), erf_abs, h);
 }
 
+// ---- GroupNorm statistics accumulated by the kernel that writes a tensor -----------------------------------------
+// A GroupNorm only ever needs per-GROUP sums, so the writer reduces its per-column sums to groups before it touches
+// memory: lane l of a wave holds (s, q) = (sum, sum of squares) over the wave's rows of output column col0 + l; the
+// columns of one group are consecutive lanes, a segmented inclusive scan over the lanes (no differences of prefix sums,
+// so nothing cancels) leaves every group's share in the last lane of its segment, and only those lanes issue the fp64
+// atomics: 2 x (groups touched) per wave instead of 2 x 64.  The group of normalised channel c is c / cpg, evaluated as
+// (c * magic) >> 32 with magic = ceil(2^32 / cpg) (exact while c * cpg < 2^32).  stats: [batch][2][ld] fp64.
+struct DmGroupStats {
+    double* sums;   // NULL = no target
+    long ld;        // doubles between the (sum | sumsq) rows: at least the number of groups
+    int ch0;        // channel index, inside the normalised tensor, of this launch's output column 0
+    int cpg;        // channels per group of the GroupNorm that will read the tensor
+    uint32_t magic;
+    int nch;        // ch0 + N: channels past it are padding columns of the tile and carry zeros
+};
+__device__ __forceinline__ void group_stats_add(const DmGroupStats& t, long b, int col0, int lane, float s, float q) {
+    const int c = t.ch0 + col0 + lane;
+    const int g = (int)__umulhi((uint32_t)c, t.magic);
+    const int seg0 = g * t.cpg - (t.ch0 + col0);  // first lane of this lane's group (negative: the group started in an earlier tile)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float su = __shfl_up(s, d), qu = __shfl_up(q, d);
+        if (lane >= d && lane - d >= seg0) {
+            s += su;
+            q += qu;
+        }
+    }
+    const bool last = lane == 63 || (int)__umulhi((uint32_t)(c + 1), t.magic) != g;
+    if (last && g * t.cpg < t.nch) {
+        double* dst = t.sums + (b * 2) * t.ld + g;
+        atomicAdd(dst, (double)s);
+        atomicAdd(dst + t.ld, (double)q);
+    }
+}
+// mean and 1 / sqrt(var + eps) of one group from its fp64 sums over n values (difference of moments in fp64)
+__device__ __forceinline__ void group_mean_rstd(double sum, double sumsq, double n, float eps, float& mean_out, float& rstd_out) {
+    const double mean = sum / n;
+    double var = sumsq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_out = (float)mean;
+    rstd_out = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 // 16-byte global load with a zero default (predicated-off lanes read nothing).
 __device__ __forceinline__ u32x4 ldg16(const void* p, bool pred) {
     u32x4 z = {0u, 0u, 0u, 0u};
@@ -175,5 +218,20 @@ static inline int dm_set_lds_attr(const void* kfn, DmLdsAttr& st, int lds_bytes)
     }
     st.devices |= 1ull << dev;
     return DM_OK;
+}
+// host side of DmGroupStats: argument check and set-up
+static inline bool dm_group_stats_ok(const double* sums, long ld, int cpg, int ch0, int n) {
+    return sums && !(reinterpret_cast<uintptr_t>(sums) & 7u) && cpg > 0 && ch0 >= 0 && (long)(ch0 + n) * cpg < (1L << 31) &&
+           ld >= (ch0 + n + cpg - 1) / cpg;
+}
+static inline DmGroupStats dm_group_stats(double* sums, long ld, int cpg, int ch0, int n) {
+    DmGroupStats t;
+    t.sums = sums;
+    t.ld = ld;
+    t.ch0 = ch0;
+    t.cpg = cpg > 0 ? cpg : 1;
+    t.magic = (uint32_t)((0x100000000ULL + (uint64_t)t.cpg - 1) / (uint64_t)t.cpg);
+    t.nch = ch0 + n;
+    return t;
 }
 static inline bool dm_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -60,13 +60,12 @@ struct GemmArgs {
     const float* ln_colsum;  // sum over k of each packed weight row (packed order)
     float ln_eps;
     double* ln_out;          // per-row (sum, sumsq) of the stored output, atomically accumulated
-    double* stats;  // per-channel (sum, sumsq) of the stored output, [batch][2][ld_stats], atomically accumulated
-    long ld_stats;
+    DmGroupStats stats, stats2;  // per-group (sum, sumsq) of the stored output for the GroupNorm(s) that read it (common.h)
     int streamk;    // stream-K: number of blocks sharing the (tile, k-tile) work list; 0 = one tile per block
     int* counters;  // stream-K: one arrival counter per output tile, zero on entry, left zero
     float* slabs;   // stream-K: 2 accumulator slabs per block
     // GroupNorm (+ SiLU) of the A operand applied to the fragments in registers (fp32, GN kernels only)
-    const double* gn_sums;  // per-channel (sum, sumsq) of A, [batch][2][ld_gn]
+    const double* gn_sums;  // per-group (sum, sumsq) of A, [batch][2][ld_gn]
     long ld_gn;
     const float* gn_gamma;
     const float* gn_beta;
@@ -272,18 +271,16 @@ __device__ __forceinline__ void mfma_tile_frags(f32x4 (&acc)[FM][4], const u32x4
 //
 // Scale / shift of the sample's C channels live in LDS behind the operand ring: scale[C] | shift[C] | scratch.
 constexpr int GN_FUSE_MAX_C = 1280;
-constexpr int GN_FUSE_SCRATCH = 64 * 8 * 2 * 8 + 2 * 64 * 4;  // partial sums (fp64) + group mean / rstd
+constexpr int GN_FUSE_SCRATCH = 2 * 64 * 4;  // group mean / rstd
 __host__ __device__ constexpr int gn_fuse_lds_bytes(int c) { return 2 * c * 4 + GN_FUSE_SCRATCH; }
 
-// Same arithmetic, in the same order, as gn_apply_kernel's statistics fold (norm.hip): 8 strided fp64 partial sums
-// per group, added in order; mean and variance in fp64.
+// Same arithmetic as gn_apply_kernel (norm.hip): mean and variance of a group from the producer's per-group fp64 sums.
 template <int NT>
 __device__ __forceinline__ void gn_build_table(const GemmArgs& p, int b, float* tab) {
     const int c = p.gn_c, groups = p.gn_groups, cpg = c / groups;
     float* t_scale = tab;
     float* t_shift = tab + c;
-    double* sub = reinterpret_cast<double*>(tab + 2 * c);       // [groups][8][2]
-    float* g_mean = reinterpret_cast<float*>(sub + 64 * 8 * 2);  // [64]
+    float* g_mean = tab + 2 * c;  // [64]
     float* g_rstd = g_mean + 64;
     const int tid = threadIdx.x;
     // affine parameters of this thread's channels, requested now: their latency overlaps the statistics fold
@@ -296,41 +293,8 @@ __device__ __forceinline__ void gn_build_table(const GemmArgs& p, int b, float* 
         bet[k] = ch < c ? p.gn_beta[ch] : 0.f;
     }
     const double* src = p.gn_sums + (long)b * 2 * p.ld_gn;
-    for (int item = tid; item < groups * 8; item += NT) {
-        const int grp = item >> 3, part = item & 7;
-        double a = 0.0, d = 0.0;
-        const int c1 = (grp + 1) * cpg;
-        for (int ch = grp * cpg + part; ch < c1; ch += 8 * 5) {  // five requests in flight, see gn_apply_kernel
-            double va[5], vd[5];
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                const int cc = ch + 8 * u;
-                va[u] = cc < c1 ? src[cc] : 0.0;
-                vd[u] = cc < c1 ? src[p.ld_gn + cc] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                a += va[u];
-                d += vd[u];
-            }
-        }
-        sub[item * 2] = a;
-        sub[item * 2 + 1] = d;
-    }
-    __syncthreads();
-    for (int grp = tid; grp < groups; grp += NT) {
-        double a = 0.0, d = 0.0;
-        for (int part = 0; part < 8; ++part) {
-            a += sub[(grp * 8 + part) * 2];
-            d += sub[(grp * 8 + part) * 2 + 1];
-        }
-        const double n = (double)p.rows_per_batch * cpg;
-        const double mean = a / n;
-        double var = d / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        g_mean[grp] = (float)mean;
-        g_rstd[grp] = (float)(1.0 / sqrt(var + (double)p.gn_eps));
-    }
+    for (int grp = tid; grp < groups; grp += NT)
+        group_mean_rstd(src[grp], src[p.ld_gn + grp], (double)p.rows_per_batch * cpg, p.gn_eps, g_mean[grp], g_rstd[grp]);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
@@ -709,7 +673,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FM][4],
                         row_q = fmaf(v, v, row_q);
                     }
             }
-            if (p.stats) {
+            if (p.stats.sums) {
                 // keep the value as stored (after rounding) in the accumulator for the statistics pass below
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -750,11 +714,12 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FM][4],
             }
         }
     }
-    if (p.stats && mrow0 < p.M) {
+    if (p.stats.sums && mrow0 < p.M) {
         // GroupNorm statistics of the tensor just written: per-channel sum and sum of squares over this
         // wave's rows, which all belong to one sample and are all valid (checked on the host).  Four columns
         // at a time (few live registers): reduce-scatter over lane bits 0-1, all-reduce over bits 2-3, then
-        // the lanes with fr>>2 == j own column 4*j + (fr&3) = fr.
+        // the lanes with fr>>2 == j own column 4*j + (fr&3) = fr, i.e. lane l owns column ngroup0 + l; those are
+        // then folded to groups and added to memory by group_stats_add.
         float own_s = 0.f, own_q = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -790,13 +755,11 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FM][4],
                 own_q = v[1][0];
             }
         }
-        const int n = ncol0 + fr;
-        if (n < p.N) {
-            const long b = mrow0 / p.rows_per_batch;
-            double* dst = p.stats + (b * 2) * p.ld_stats + n;
-            atomicAdd(dst, (double)own_s);
-            atomicAdd(dst + p.ld_stats, (double)own_q);
-        }
+        if (ncol0 + fr >= p.N) own_s = own_q = 0.f;  // padding columns of the tile
+        const long b = mrow0 / p.rows_per_batch;
+        const int lane = fq * 16 + fr;
+        group_stats_add(p.stats, b, ngroup0, lane, own_s, own_q);
+        if (p.stats2.sums) group_stats_add(p.stats2, b, ngroup0, lane, own_s, own_q);
     }
 }
 
@@ -2150,7 +2113,9 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     if (d->epi == DM_EPI_GEGLU && (!d->bias || d->n % 64 || d->rowbias || d->r)) return DM_ERR_ARG;
     if (d->epi == DM_EPI_QUICKGELU && d->r) return DM_ERR_ARG;  // activation of a sum with a residual is not a thing here
     if ((d->rowbias || d->epi == DM_EPI_NCHW_F32 || d->stats) && d->rows_per_batch <= 0) return DM_ERR_ARG;
-    if (d->stats && (d->epi != DM_EPI_PLAIN || (reinterpret_cast<uintptr_t>(d->stats) & 7u) || d->ld_stats < d->n))
+    if (d->stats && (d->epi != DM_EPI_PLAIN || !dm_group_stats_ok(d->stats, d->ld_stats, d->stats_cpg, d->stats_ch0, d->n)))
+        return DM_ERR_ARG;
+    if (d->stats2 && (!d->stats || !dm_group_stats_ok(d->stats2, d->ld_stats2, d->stats2_cpg, d->stats2_ch0, d->n)))
         return DM_ERR_ARG;
 
     int tile = d->tile, splitk = d->splitk;
@@ -2188,7 +2153,7 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
         // GroupNorm of A inside the launch: every tile lies in one sample, whole k-tiles of normalised channels
         gn_c = d->conv ? d->cin : (d->a2 ? d->k - d->cin2 : d->k);
         if (!dm_gemm_gn_supported(d->dtype, tile, d->conv, gn_c, d->gn_groups, d->rows_per_batch, splitk)) return DM_ERR_ARG;
-        if (!d->gn_gamma || !d->gn_beta || (reinterpret_cast<uintptr_t>(d->gn_sums) & 7u) || d->ld_gn < gn_c ||
+        if (!d->gn_gamma || !d->gn_beta || (reinterpret_cast<uintptr_t>(d->gn_sums) & 7u) || d->ld_gn < d->gn_groups ||
             d->m % d->rows_per_batch || d->ln_in)
             return DM_ERR_ARG;
         if (d->conv ? (d->stride != 1 || d->up || d->pad_hi_only || d->hin != d->hout || d->win != d->wout || !d->gn_silu ||
@@ -2233,8 +2198,8 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     a.epi = d->epi;
     a.splitk = splitk;
     a.partial = static_cast<float*>(d->workspace);
-    a.stats = d->stats;
-    a.ld_stats = d->ld_stats;
+    a.stats = dm_group_stats(d->stats, d->ld_stats, d->stats_cpg, d->stats_ch0, d->n);
+    a.stats2 = dm_group_stats(d->stats2, d->ld_stats2, d->stats2_cpg, d->stats2_ch0, d->n);
     a.ln_in = d->ln_in;
     a.ln_colsum = d->ln_colsum;
     a.ln_eps = d->ln_eps;

@@ -17,7 +17,7 @@ namespace {
 constexpr int GN_THREADS = 256;
 constexpr int GN_MAX_SLOTS = 3;   // chunks per thread per row
 constexpr int GN_UNROLL = 4;      // rows in flight per thread
-constexpr int GN_MAX_C = 4096;    // 2 fp32 LDS tables of C entries + the reduction scratch stay under 64 KB
+constexpr int GN_MAX_C = 4096;    // widest tensor: 3 chunk slots of 256 threads (bf16: 8 channels per chunk)
 
 struct GnGeom {
     int nchunks, slots, tpr, rpi;  // chunks per row, chunk slots per thread, threads per row, rows per iteration
@@ -128,99 +128,79 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
                                                                const float* __restrict__ beta, float eps, int silu,
                                                                int rows_per_block) {
     constexpr int EPC = ElemTraits<T>::EPC;
-    extern __shared__ __attribute__((aligned(16))) float tab[];  // scale[c] | shift[c]: y = x*scale + shift
-    float* t_scale = tab;
-    float* t_shift = tab + c;
     __shared__ float g_mean[64], g_rstd[64];
+    __shared__ double sub[64][8][2];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int cpg = c / groups;
-    // affine parameters of this thread's channels, requested now so that their latency overlaps the statistics
-    // loads below instead of following the second barrier
-    constexpr int CH_PER_THREAD = GN_MAX_C / GN_THREADS;
-    float gam[CH_PER_THREAD], bet[CH_PER_THREAD];
+    const GnGeom g = gn_geom<T>(c);
+    const int lir = tid % g.tpr, rl = tid / g.tpr;
+    // A thread owns the same channel chunks on every row.  Their affine parameters are requested first, so that their
+    // latency overlaps the statistics below.
+    float gam[GN_MAX_SLOTS][EPC], bet[GN_MAX_SLOTS][EPC];
 #pragma unroll
-    for (int k = 0; k < CH_PER_THREAD; ++k) {
-        const int ch = tid + k * GN_THREADS;
-        gam[k] = ch < c ? gamma[ch] : 0.f;
-        bet[k] = ch < c ? beta[ch] : 0.f;
-    }
-    // fold the slab partials: 8 threads per group each sum a strided subset in fp64 (fixed order),
-    // then the group's first thread adds the 8 sub-sums in order
-    __shared__ double sub[64][8][2];
-    for (int item = tid; item < groups * 8; item += GN_THREADS) {
-        const int grp = item >> 3, part = item & 7;
-        double a = 0.0, d = 0.0;
-        if (sums) {
-            // per-channel sums accumulated by the kernel that wrote x.  Five strided channels are requested before the
-            // first is added (a loop of load - wait - add pays one memory latency per channel: five in a row at 1280
-            // channels, and this fold is the serial head of every block); lanes past the group add zero, so the
-            // order of the real additions is unchanged.
-            const double* src = sums + (long)b * 2 * ld_sums;
-            const int c1 = (grp + 1) * cpg;
-            for (int ch = grp * cpg + part; ch < c1; ch += 8 * 5) {
-                double va[5], vd[5];
+    for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+        const int chunk = lir + k * g.tpr;
+        const bool ok = rl < g.rpi && k < g.slots && chunk < g.nchunks;
 #pragma unroll
-                for (int u = 0; u < 5; ++u) {
-                    const int cc = ch + 8 * u;
-                    va[u] = cc < c1 ? src[cc] : 0.0;
-                    vd[u] = cc < c1 ? src[ld_sums + cc] : 0.0;
-                }
+        for (int e4 = 0; e4 < EPC; e4 += 4) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 gv = ok ? *reinterpret_cast<const f32x4*>(gamma + chunk * EPC + e4) : zero;
+            const f32x4 bv = ok ? *reinterpret_cast<const f32x4*>(beta + chunk * EPC + e4) : zero;
 #pragma unroll
-                for (int u = 0; u < 5; ++u) {
-                    a += va[u];
-                    d += vd[u];
-                }
+            for (int e = 0; e < 4; ++e) {
+                gam[k][e4 + e] = gv[e];
+                bet[k][e4 + e] = bv[e];
             }
-        } else {
+        }
+    }
+    if (sums) {
+        // per-group sums accumulated by the kernel that wrote x: one thread per group, two 8-byte reads each - no fold
+        const double* src = sums + (long)b * 2 * ld_sums;
+        for (int grp = tid; grp < groups; grp += GN_THREADS)
+            group_mean_rstd(src[grp], src[ld_sums + grp], (double)hw * cpg, eps, g_mean[grp], g_rstd[grp]);
+    } else {
+        // fold the slab partials: 8 threads per group each sum a strided subset in fp64 (fixed order),
+        // then the group's first thread adds the 8 sub-sums in order
+        for (int item = tid; item < groups * 8; item += GN_THREADS) {
+            const int grp = item >> 3, part = item & 7;
+            double a = 0.0, d = 0.0;
             for (int sp = part; sp < nsplit; sp += 8) {
                 const float* src = partial + (((long)b * nsplit + sp) * groups + grp) * 2;
                 a += (double)src[0];
                 d += (double)src[1];
             }
+            sub[grp][part][0] = a;
+            sub[grp][part][1] = d;
         }
-        sub[grp][part][0] = a;
-        sub[grp][part][1] = d;
-    }
-    __syncthreads();
-    for (int grp = tid; grp < groups; grp += GN_THREADS) {
-        double a = 0.0, d = 0.0;
-        for (int part = 0; part < 8; ++part) {
-            a += sub[grp][part][0];
-            d += sub[grp][part][1];
-        }
-        const double n = (double)hw * cpg;
-        const double mean = a / n;
-        double var = d / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        g_mean[grp] = (float)mean;
-        g_rstd[grp] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < CH_PER_THREAD; ++k) {
-        const int ch = tid + k * GN_THREADS;
-        if (ch < c) {
-            const int grp = ch / cpg;
-            const float sc = g_rstd[grp] * gam[k];
-            t_scale[ch] = sc;
-            t_shift[ch] = fmaf(-g_mean[grp], sc, bet[k]);
+        __syncthreads();
+        for (int grp = tid; grp < groups; grp += GN_THREADS) {
+            double a = 0.0, d = 0.0;
+            for (int part = 0; part < 8; ++part) {
+                a += sub[grp][part][0];
+                d += sub[grp][part][1];
+            }
+            group_mean_rstd(a, d, (double)hw * cpg, eps, g_mean[grp], g_rstd[grp]);
         }
     }
     __syncthreads();
-
-    const GnGeom g = gn_geom<T>(c);
-    const int lir = tid % g.tpr, rl = tid / g.tpr;
     if (rl >= g.rpi) return;
-    // a thread owns the same channel chunks on every row: keep their scale / shift in registers
+    // y = x * scale + shift with scale = rstd * gamma, shift = beta - mean * scale, kept in registers
     float sc[GN_MAX_SLOTS][EPC], sh[GN_MAX_SLOTS][EPC];
 #pragma unroll
     for (int k = 0; k < GN_MAX_SLOTS; ++k) {
         const int chunk = lir + k * g.tpr;
         const bool ok = k < g.slots && chunk < g.nchunks;
+        // one division per chunk; the group index then follows the channel index
+        int grp = ok ? (chunk * EPC) / cpg : 0;
+        int rem = ok ? chunk * EPC - grp * cpg : 0;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            sc[k][e] = ok ? t_scale[chunk * EPC + e] : 0.f;
-            sh[k][e] = ok ? t_shift[chunk * EPC + e] : 0.f;
+            sc[k][e] = g_rstd[grp] * gam[k][e];
+            sh[k][e] = fmaf(-g_mean[grp], sc[k][e], bet[k][e]);
+            if (ok && ++rem == cpg) {
+                rem = 0;
+                ++grp;
+            }
         }
     }
     const int r0 = blockIdx.x * rows_per_block, r1 = min(hw, r0 + rows_per_block);
@@ -387,7 +367,7 @@ int gn_apply_launch(const void* x, long ldx, void* y, long ldy, int batch, int h
     int rows_per_block = (hw + want - 1) / want;
     if (rows_per_block < g.rpi) rows_per_block = g.rpi;
     const int nb = (hw + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(nb, batch), dim3(GN_THREADS), 2 * c * sizeof(float), s,
+    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(nb, batch), dim3(GN_THREADS), 0, s,
                        static_cast<const T*>(x), ldx, static_cast<T*>(y), ldy, hw, c, groups, partial, nsplit, sums,
                        ld_sums, gamma, beta, eps, silu, rows_per_block);
     return dm_check_launch();
@@ -469,8 +449,8 @@ extern "C" int dm_groupnorm_apply(const void* x, long ldx, void* y, long ldy, in
 extern "C" int dm_groupnorm_apply_sums(const void* x, long ldx, void* y, long ldy, int batch, int hw, int c, int groups,
                                        int dtype, const double* sums, long ld_sums, const float* gamma,
                                        const float* beta, float eps, int silu, hipStream_t stream) {
-    if (!norm_args_ok(x, ldx, y, ldy, c, dtype) || !y || !sums || ld_sums < c || !gamma || !beta || batch <= 0 ||
-        hw <= 0 || groups <= 0 || groups > 64 || c % groups)
+    if (!norm_args_ok(x, ldx, y, ldy, c, dtype) || !y || !sums || ld_sums < groups || !gamma || !beta || batch <= 0 ||
+        hw <= 0 || groups <= 0 || groups > 64 || c % groups || (reinterpret_cast<uintptr_t>(sums) & 7u))
         return DM_ERR_ARG;
     return dtype == DM_F32
                ? gn_apply_launch<float>(x, ldx, y, ldy, batch, hw, c, groups, nullptr, 0, sums, ld_sums, gamma, beta, eps, silu, stream)

@@ -48,8 +48,7 @@ struct PanelArgs {
     float ln_eps;
     double* ln_out;          // per-row (sum, sumsq) of the stored output
     int ln_out_atomic;       // grid.y > 1: several blocks contribute to a row
-    double* stats;           // per-channel (sum, sumsq) of the stored output, [batch][2][ld_stats]
-    long ld_stats;
+    DmGroupStats stats, stats2;  // per-group (sum, sumsq) of the stored output (common.h)
     int rows_per_batch;
 };
 
@@ -266,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void gemm_panel_kernel(PanelArgs p) {
             u32x4 pk[2];
 #pragma unroll
             for (int q = 0; q < 8; ++q) pk[q >> 2][q & 3] = pack_bf16x2(o[2 * q], o[2 * q + 1]);
-            if (p.ln_out || p.stats) {
+            if (p.ln_out || p.stats.sums) {
                 // statistics are taken of the values as stored (after rounding)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -284,10 +283,11 @@ __global__ __launch_bounds__(256, 2) void gemm_panel_kernel(PanelArgs p) {
             *reinterpret_cast<u32x4*>(dst) = pk[0];
             *reinterpret_cast<u32x4*>(dst + 8) = pk[1];
         }
-        if (p.stats && mrow0 < p.M) {
+        if (p.stats.sums && mrow0 < p.M) {
             // GroupNorm statistics of the tensor just written: per-channel sums over this wave's rows (all of one sample and
             // all valid: checked on the host).  Four columns at a time: reduce-scatter over lane bits 0-1, all-reduce over
-            // bits 2-3, then the lanes with fr>>2 == j own column 4 j + (fr & 3) = fr.
+            // bits 2-3, then the lanes with fr>>2 == j own column 4 j + (fr & 3) = fr, i.e. lane l owns column n0 + l;
+            // group_stats_add folds them to groups and adds the groups' shares to memory.
             float own_s = 0.f, own_q = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -324,9 +324,8 @@ __global__ __launch_bounds__(256, 2) void gemm_panel_kernel(PanelArgs p) {
                 }
             }
             const long b = mrow0 / p.rows_per_batch;
-            double* dst = p.stats + (b * 2) * p.ld_stats + ncol0 + fr;
-            atomicAdd(dst, (double)own_s);
-            atomicAdd(dst + p.ld_stats, (double)own_q);
+            group_stats_add(p.stats, b, n0, lane, own_s, own_q);
+            if (p.stats2.sums) group_stats_add(p.stats2, b, n0, lane, own_s, own_q);
         }
     }
     if (p.ln_out) {
@@ -410,8 +409,8 @@ int dm_panel_launch(const DmGemmDesc* d, int tile, int nsplit, hipStream_t strea
     a.ln_eps = d->ln_eps;
     a.ln_out = d->ln_out;
     a.ln_out_atomic = nsplit > 1;
-    a.stats = d->stats;
-    a.ld_stats = d->ld_stats;
+    a.stats = dm_group_stats(d->stats, d->ld_stats, d->stats_cpg, d->stats_ch0, d->n);
+    a.stats2 = dm_group_stats(d->stats2, d->ld_stats2, d->stats2_cpg, d->stats2_ch0, d->n);
     a.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : 1;
     const bool k5 = d->k == 320;
     switch (tile) {

@@ -122,8 +122,9 @@ class Engine:
         # work-list (stream-K) GEMMs: arrival counters + accumulator slabs; the counters must read zero
         # at every launch (the kernel leaves them zero), so this buffer is never shared with the slabs above
         self.ws_sk = torch.zeros(160 << 20, dtype=torch.uint8, device=device)
-        # GroupNorm statistics accumulated by the producing GEMM: per-channel fp64 (sum, sumsq), [batch][2][C].
-        # Regions are handed out bump-style per forward and the used prefix is zeroed by reset().
+        # GroupNorm statistics accumulated by the producing GEMM: per-group fp64 (sum, sumsq), [batch][2][32], and the
+        # per-row (sum, sumsq) of tensors a folded LayerNorm reads.  Regions are handed out bump-style per forward and
+        # the used prefix is zeroed by reset().
         self.stats_buf = torch.zeros(8 << 20, dtype=torch.float64, device=device)
         self._stats_off = 0    # elements handed out since the last reset
         self._stats_dirty = 0  # high-water mark of elements that may be non-zero
@@ -227,45 +228,47 @@ class Engine:
         self._stats_dirty = max(self._stats_dirty, self._stats_off)
         return t
 
+    GN_GROUPS = 32  # every GroupNorm of the U-Net and of the autoencoder has 32 groups; others take the two-launch form
+
+    def _gn_record(self, t: torch.Tensor, batch: int) -> dict:
+        """Bookkeeping of one tensor whose per-group sums are accumulated by the GEMM(s) that write it: the kernels reduce
+        their column sums to the groups of the GroupNorm that reads the tensor, [batch][2][groups] fp64."""
+        cols = t.shape[1]
+        return dict(base=t.data_ptr(), ld=t.stride(0), cols=cols, rows=t.shape[0], batch=batch, groups=self.GN_GROUPS,
+                    cpg=cols // self.GN_GROUPS, stats=self._stats_alloc(batch, self.GN_GROUPS),
+                    valid=cols % self.GN_GROUPS == 0, parts=0)
+
     def gn_register(self, buf: torch.Tensor, batch: int):
         """Announce a buffer whose channel slices are written by several GEMMs and then group-normalised whole."""
         if not self.fuse_gn_stats:
             return
-        self._gn_shared.append(dict(base=buf.data_ptr(), ld=buf.stride(0), cols=buf.shape[1], rows=buf.shape[0],
-                                    batch=batch, stats=self._stats_alloc(batch, buf.shape[1]), valid=True, parts=0))
+        self._gn_shared.append(self._gn_record(buf, batch))
 
-    def _gn_target(self, out: torch.Tensor, batch: int):
-        """(record, channel offset) that a GEMM writing `out` accumulates its statistics into."""
+    def _gn_targets(self, out: torch.Tensor, batch: int):
+        """[(record, channel offset)] that a GEMM writing `out` accumulates its statistics into: the tensor itself, and
+        the shared buffer it is a channel slice of (if any) - the two GroupNorms that may read it partition its
+        channels into different groups."""
         p, ld = out.data_ptr(), out.stride(0)
-        for rec in self._gn_shared:
-            if rec["ld"] == ld and rec["base"] <= p < rec["base"] + ld * self.esz and rec["rows"] == out.shape[0]:
-                return rec, (p - rec["base"]) // self.esz
-        rec = dict(base=p, ld=ld, cols=out.shape[1], rows=out.shape[0], batch=batch,
-                   stats=self._stats_alloc(batch, out.shape[1]), valid=True, parts=0)
+        rec = self._gn_record(out, batch)
         self._gn_auto[p] = rec
-        return rec, 0
+        targets = [(rec, 0)]
+        for sh in self._gn_shared:
+            if sh["ld"] == ld and sh["base"] <= p < sh["base"] + ld * self.esz and sh["rows"] == out.shape[0]:
+                targets.append((sh, (p - sh["base"]) // self.esz))
+                break
+        return targets
 
-    def _gn_lookup(self, x: torch.Tensor, batch: int):
+    def _gn_lookup(self, x: torch.Tensor, batch: int, groups: int = 32):
+        """Statistics of `x` (the input of a GroupNorm with `groups` groups) if the launches that wrote it accumulated
+        all of them: the tensor's own record, or the shared buffer's when `x` is such a buffer as a whole."""
         p = x.data_ptr()
-        rec = self._gn_auto.get(p)
-        if rec is None:
-            for r in self._gn_shared:
-                if r["base"] == p:
-                    rec = r
-                    break
-        if rec is None:
-            # a channel slice of a shared buffer (an encoder output that lives inside a decoder's concat buffer):
-            # usable when one producer accumulated exactly that slice
-            for r in self._gn_shared:
-                off = (p - r["base"]) // self.esz
-                if (r["valid"] and r["ld"] == x.stride(0) and r["rows"] == x.shape[0] and r["batch"] == batch
-                        and r["base"] < p < r["base"] + r["ld"] * self.esz and (off, x.shape[1]) in r.get("ranges", ())):
-                    return dict(stats_ptr=r["stats"].data_ptr() + off * 8, ld=r["cols"])
-            return None
-        if (not rec["valid"] or rec["ld"] != x.stride(0) or rec["cols"] != x.shape[1]
-                or rec["rows"] != x.shape[0] or rec["batch"] != batch or rec["parts"] != rec["cols"]):
-            return None
-        return dict(stats_ptr=rec["stats"].data_ptr(), ld=rec["cols"])
+        cands = [self._gn_auto.get(p)] + [r for r in self._gn_shared if r["base"] == p]
+        for rec in cands:
+            if (rec is not None and rec["valid"] and rec["groups"] == groups and rec["ld"] == x.stride(0)
+                    and rec["cols"] == x.shape[1] and rec["rows"] == x.shape[0] and rec["batch"] == batch
+                    and rec["parts"] == rec["cols"]):
+                return dict(stats_ptr=rec["stats"].data_ptr(), ld=rec["groups"], rec=rec)
+        return None
 
     # ------------------------------------------------------------------ weight packing
     def _order(self, n: int, npad: int, geglu: bool) -> torch.Tensor:
@@ -405,7 +408,7 @@ class Engine:
                     and a2 is None
                     and (conv is None or pw.n <= self.fuse_gn_conv_max_n)
                     and (conv is not None) == bool(gn_in["silu"]) and c_gn % 32 == 0 and c_gn <= 1280):
-                gn_rec = self._gn_lookup(a, gn_in["batch"])
+                gn_rec = self._gn_lookup(a, gn_in["batch"], gn_in.get("groups", 32))
             if gn_rec is None:
                 a = self._gn_unfused(a, gn_in)
         if conv is not None:
@@ -511,18 +514,23 @@ class Engine:
         elif sk.value < 0:
             self._bind_streamk(d, tile.value, m, pw.n, -sk.value)
         if gn_batch > 0 and self.fuse_gn_stats and nchw_out is None and not pw.geglu:
-            rec, ch_off = self._gn_target(out, gn_batch)
+            targets = self._gn_targets(out, gn_batch)
             hw = m // gn_batch
             ok = (m % gn_batch == 0 and (rows_per_batch in (0, hw)) and tile.value != _lib.TILE_AUTO
                   and self.lib.dm_gemm_stats_supported(tile.value, hw, sk.value))
-            if ok:
-                d.stats = rec["stats"].data_ptr() + ch_off * 8
-                d.ld_stats = rec["cols"]
+            live = [(rec, off) for rec, off in targets if ok and rec["valid"]]
+            for rec, off in targets:
+                if (rec, off) in live:
+                    rec["parts"] += n_out
+                else:
+                    rec["valid"] = False
+            if live:
                 d.rows_per_batch = hw
-                rec["parts"] += pw.n
-                rec.setdefault("ranges", []).append((ch_off, n_out))
-            else:
-                rec["valid"] = False
+                (r1, o1) = live[0]
+                d.stats, d.ld_stats, d.stats_cpg, d.stats_ch0 = r1["stats"].data_ptr(), r1["groups"], r1["cpg"], o1
+                if len(live) > 1:
+                    (r2, o2) = live[1]
+                    d.stats2, d.ld_stats2, d.stats2_cpg, d.stats2_ch0 = r2["stats"].data_ptr(), r2["groups"], r2["cpg"], o2
         with self._prof(klass, 2.0 * m * pw.n * (pw.k if conv is None else 9 * conv["cin_real"] + pw.skip_cin),
                         f"m={m} n={pw.n} k={pw.k} tile={tile.value} sk={sk.value} epi={d.epi}"
                         + (f" s={d.stride} up={d.up}" if conv is not None else "")):
@@ -732,7 +740,7 @@ class Engine:
     def groupnorm(self, x: torch.Tensor, batch: int, hw: int, gamma, beta, eps: float, silu: bool,
                   out: Optional[torch.Tensor] = None, groups: int = 32) -> torch.Tensor:
         c = x.shape[1]
-        rec = self._gn_lookup(x, batch)
+        rec = self._gn_lookup(x, batch, groups)
         if out is None:
             out = self.new(batch * hw, c)
         if rec is not None:

@@ -111,12 +111,22 @@ typedef struct DmGemmDesc {
                            * >= dm_gemm_streamk_workspace_bytes(), whose leading arrival counters must read zero
                            * at launch (the kernel leaves them zero) - do not share it with split-K slabs */
     long workspace_bytes;
-    double* stats;        /* NULL, or per-channel sums of the STORED output for a following GroupNorm:
-                           * stats[(b*2 + 0)*ld_stats + n] += sum over the rows of sample b of c[m][n],
-                           * stats[(b*2 + 1)*ld_stats + n] += the same of c[m][n]^2 (atomic adds; the caller
-                           * zeroes the buffer).  Needs rows_per_batch, the plain epilogue, no split-K reduction
-                           * launch, and dm_gemm_stats_supported(tile, rows_per_batch, splitk) != 0. */
-    long ld_stats;
+    double* stats;        /* NULL, or per-GROUP sums of the STORED output for the GroupNorm that reads it next: output
+                           * column n is channel stats_ch0 + n of the normalised tensor (the output may be a channel
+                           * slice of it) and belongs to group g = (stats_ch0 + n) / stats_cpg;
+                           * stats[(b*2 + 0)*ld_stats + g] += sum over the rows of sample b of c[m][n],
+                           * stats[(b*2 + 1)*ld_stats + g] += the same of c[m][n]^2 (fp64 atomic adds, two per group
+                           * and wave; the caller zeroes the buffer).  Needs rows_per_batch, the plain epilogue, no
+                           * split-K reduction launch, and dm_gemm_stats_supported(tile, rows_per_batch, splitk) != 0. */
+    long ld_stats;        /* >= number of groups of the normalised tensor */
+    int stats_cpg;        /* channels per group */
+    int stats_ch0;
+    double* stats2;       /* NULL, or a second partition of the same columns (an encoder output that is normalised on
+                           * its own by the next stage AND as the right-hand slice of a decoder's concatenated input):
+                           * same meaning with its own ld / cpg / ch0; needs stats */
+    long ld_stats2;
+    int stats2_cpg;
+    int stats2_ch0;
     /* LayerNorm folded into the GEMMs on either side of it (blocks.py:137-138,143-144,149-150):
      * ln_out: the producer adds, per output row m, sum and sum of squares of the stored row to
      *         ln_out[2m], ln_out[2m+1] (fp64 atomics; caller zeroes; plain epilogue; no split-K launch);
@@ -146,8 +156,8 @@ typedef struct DmGemmDesc {
     /* GroupNorm (+ SiLU) of the A operand applied inside this launch (NULL = none; fp32 only): the tensor `a` is the
      * INPUT of nn.GroupNorm(gn_groups, C) (blocks.py:58-59,68-69,128; diffusion.py:44-45) and the product is taken
      * over silu(groupnorm(a)) (conv) / groupnorm(a) (dense) without that tensor ever being written.  gn_sums are the
-     * per-channel fp64 (sum, sumsq) of `a`, [batch][2][ld_gn], as accumulated through `stats` by the launch that wrote
-     * it.  Every block folds them to per-channel scale / shift in LDS and applies them to its A fragments in
+     * per-group fp64 (sum, sumsq) of `a`, [batch][2][ld_gn], as accumulated through `stats` by the launch that wrote
+     * it.  Every block turns them into per-channel scale / shift in LDS and applies them to its A fragments in
      * registers; padding taps stay zero, the appended operand `a2` is not normalised.  Needs a direct-to-LDS tile
      * (DM_TILE_D*), C = cin (conv) or k - cin2 (dense) a multiple of 32 and of gn_groups and at most 1280,
      * rows_per_batch a multiple of the tile's rows, stride 1 / same size / no upsampling, gn_silu = 1 for conv and
@@ -198,8 +208,8 @@ int dm_pack_rows(const void* src, long ld, int n, int k, int transposed, void* d
 /* GroupNorm (+ optional SiLU) over NHWC rows.  Replaces nn.GroupNorm(32, C) + F.silu
  * (blocks.py:58-59,68-69,128; diffusion.py:44-45).  Two launches: per-slab (sum, sumsq)
  * partials, then normalise.  partial: fp32 [batch][nsplit][groups][2].
- * dm_groupnorm_apply_sums: one launch; the statistics come from the per-channel fp64 sums that
- * dm_gemm accumulated while it wrote x (DmGemmDesc.stats: [batch][2][ld_sums]). */
+ * dm_groupnorm_apply_sums: one launch; the statistics come from the per-group fp64 sums that
+ * dm_gemm accumulated while it wrote x (DmGemmDesc.stats: [batch][2][ld_sums], ld_sums >= groups). */
 int dm_groupnorm_stats(const void* x, long ldx, int batch, int hw, int c, int groups, int dtype,
                        float* partial, int nsplit, hipStream_t stream);
 int dm_groupnorm_apply(const void* x, long ldx, void* y, long ldy, int batch, int hw, int c, int groups,

@@ -183,6 +183,12 @@ def test_gemm_fused_groupnorm_statistics(eng, tile, sk):
     y = rnd(y, eng.dtype).reshape(b, hw, n1 + n2).permute(0, 2, 1)
     ref = F.silu(F.group_norm(y, 32, gamma, beta, eps=1e-5)).permute(0, 2, 1).reshape(m, n1 + n2)
     assert max_rel(out.float(), ref) < (2e-5 if eng.dtype == torch.float32 else 2e-2)
+    # the right-hand slice is also normalised on its own (an encoder output read by the next encoder stage): the same
+    # launch accumulated a second partition of its columns into groups of 160 / 32 channels
+    assert eng._gn_lookup(buf[:, n1:], b) is not None, "the slice's own statistics were not fused"
+    out2 = eng.groupnorm(buf[:, n1:], b, hw, gamma[n1:].contiguous().to(eng.device), beta[n1:].contiguous().to(eng.device), 1e-5, False)
+    ref2 = F.group_norm(y[:, n1:], 32, gamma[n1:], beta[n1:], eps=1e-5).permute(0, 2, 1).reshape(m, n2)
+    assert max_rel(out2.float(), ref2) < (2e-5 if eng.dtype == torch.float32 else 2e-2)
 
 
 GN_TILES = (_lib.TILE_D128x128_S2, _lib.TILE_D64x128_S3, _lib.TILE_D64x64_S4, _lib.TILE_D32x64_S4, _lib.TILE_D128x64_S2,
