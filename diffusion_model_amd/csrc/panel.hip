@@ -50,6 +50,14 @@ struct PanelArgs {
     int ln_out_atomic;       // grid.y > 1: several blocks contribute to a row
     DmGroupStats stats, stats2;  // per-group (sum, sumsq) of the stored output (common.h)
     int rows_per_batch;
+    // GroupNorm (no activation) of the A operand applied to the block's rows as they are loaded: A is the INPUT of the
+    // GroupNorm, gn_sums its per-group (sum, sumsq) [batch][2][ld_gn] from the launch that wrote it
+    const double* gn_sums;
+    long ld_gn;
+    const float* gn_gamma;
+    const float* gn_beta;
+    float gn_eps;
+    int gn_groups;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -126,6 +134,29 @@ __global__ __launch_bounds__(256, 2) void gemm_panel_kernel(PanelArgs p) {
         }
     }
 
+    // ---- GroupNorm of the A operand: per-channel scale = rstd * gamma and shift = beta - mean * scale of the block's sample
+    // (all rows of a block lie in one sample: checked on the host), in LDS behind the column-term table
+    float* const gn_tab = tab + (jt1 - jt0) * 128;  // scale[K] | shift[K] | group mean[64] | group rstd[64]
+    if (p.gn_sums) {
+        constexpr int KC = KT * 64;
+        float* g_mean = gn_tab + 2 * KC;
+        float* g_rstd = g_mean + 64;
+        const int cpg = KC / p.gn_groups;
+        const double* src = p.gn_sums + (long)(m0 / p.rows_per_batch) * 2 * p.ld_gn;
+        if (tid < p.gn_groups)
+            group_mean_rstd(src[tid], src[p.ld_gn + tid], (double)p.rows_per_batch * cpg, p.gn_eps, g_mean[tid], g_rstd[tid]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int c = tid; c < KC; c += 256) {
+            const int grp = c / cpg;
+            const float sc = g_rstd[grp] * p.gn_gamma[c];
+            gn_tab[c] = sc;
+            gn_tab[KC + c] = fmaf(-g_mean[grp], sc, p.gn_beta[c]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
     // ---- the block's A rows, once, into registers: fragment (i, ks) of lane (fr, fq) = row mrow0 + 16 i + fr,
     // k = 32 ks + 8 fq .. + 8 (16 bytes)
     u32x4 afr[FM][2 * KT];
@@ -138,6 +169,26 @@ __global__ __launch_bounds__(256, 2) void gemm_panel_kernel(PanelArgs p) {
         for (int ks = 0; ks < 2 * KT; ++ks) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(ap + ks * 64);
             afr[i][ks] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    if (p.gn_sums) {
+        // the map runs once per element of A: the rows stay in registers for every column tile
+#pragma unroll
+        for (int ks = 0; ks < 2 * KT; ++ks) {
+            const float* sc = gn_tab + ks * 32 + fq * 8;
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(sc + KT * 64), t1 = *reinterpret_cast<const f32x4*>(sc + KT * 64 + 4);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                float f[8];
+                chunk_to_f32<bf16_t>(afr[i][ks], f);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f[e] = fmaf(f[e], s0[e], t0[e]);
+                    f[4 + e] = fmaf(f[4 + e], s1[e], t1[e]);
+                }
+                afr[i][ks] = f32_to_chunk<bf16_t>(f);
+            }
         }
     }
     // folded LayerNorm in front: mean and 1/sqrt(var + eps) of this lane's rows (difference of moments in fp64)
@@ -355,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void gemm_panel_kernel(PanelArgs p) {
 template <int FM, int KT, int STAGES> int launch(const PanelArgs& a, int nsplit, hipStream_t stream) {
     static DmLdsAttr attr;
     auto kfn = gemm_panel_kernel<FM, KT, STAGES>;
-    const int lds = STAGES * SLOT + a.per_split * 512;  // ring + the column-term table
+    const int lds = STAGES * SLOT + a.per_split * 512 + (a.gn_sums ? (2 * KT * 64 + 128) * 4 : 0);  // ring + column terms + GroupNorm table
     if (lds > 160 * 1024) return DM_ERR_ARG;
     if (const int rc = dm_set_lds_attr(reinterpret_cast<const void*>(kfn), attr, 160 * 1024)) return rc;
     const dim3 grid((a.M + 64 * FM - 1) / (64 * FM), nsplit, 1);
@@ -375,7 +426,14 @@ int dm_panel_rows(int tile) {
 
 int dm_panel_supported(const DmGemmDesc* d, int tile, int nsplit) {
     const int bm = dm_panel_rows(tile);
-    if (!bm || d->dtype != DM_BF16 || d->conv || d->a2 || d->rowbias || d->gn_sums || d->w_split) return 0;
+    if (!bm || d->dtype != DM_BF16 || d->conv || d->a2 || d->rowbias || d->w_split) return 0;
+    if (d->gn_sums) {
+        // GroupNorm of A inside the launch: affine only (no SiLU), every block inside one sample
+        if (d->gn_silu || d->ln_in || !d->gn_gamma || !d->gn_beta || (reinterpret_cast<uintptr_t>(d->gn_sums) & 7u) ||
+            d->gn_groups <= 0 || d->gn_groups > 64 || d->k % d->gn_groups || d->ld_gn < d->gn_groups ||
+            d->rows_per_batch <= 0 || d->rows_per_batch % bm || d->m % d->rows_per_batch)
+            return 0;
+    }
     if (d->k != d->kpad || (d->k != 320 && d->k != 640)) return 0;
     if (tile == DM_TILE_P128 && d->k != 320) return 0;  // 32 rows per wave: the fragments of K = 640 do not fit the registers
     if (d->n % 64 || (d->epi != DM_EPI_PLAIN && d->epi != DM_EPI_GEGLU)) return 0;
@@ -412,6 +470,12 @@ int dm_panel_launch(const DmGemmDesc* d, int tile, int nsplit, hipStream_t strea
     a.stats = dm_group_stats(d->stats, d->ld_stats, d->stats_cpg, d->stats_ch0, d->n);
     a.stats2 = dm_group_stats(d->stats2, d->ld_stats2, d->stats2_cpg, d->stats2_ch0, d->n);
     a.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : 1;
+    a.gn_sums = d->gn_sums;
+    a.ld_gn = d->ld_gn;
+    a.gn_gamma = d->gn_gamma;
+    a.gn_beta = d->gn_beta;
+    a.gn_eps = d->gn_eps;
+    a.gn_groups = d->gn_groups;
     const bool k5 = d->k == 320;
     switch (tile) {
         case DM_TILE_P64: return k5 ? launch<1, 5, PANEL_STAGES>(a, nsplit, stream) : launch<1, 10, PANEL_STAGES>(a, nsplit, stream);

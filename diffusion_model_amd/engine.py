@@ -404,10 +404,14 @@ class Engine:
             geom_ok = conv is None or (conv.get("stride", 1) == 1 and not conv.get("up", 0)
                                        and not conv.get("pad_hi_only", 0) and conv["hin"] == conv["hout"]
                                        and conv["win"] == conv["wout"] and conv["hout"] * conv["wout"] == gn_in["hw"])
-            if (self.fuse_gn_apply and not pw.split and self.dtype == torch.float32 and geom_ok and ln_in is None
-                    and a2 is None
-                    and (conv is None or pw.n <= self.fuse_gn_conv_max_n)
-                    and (conv is not None) == bool(gn_in["silu"]) and c_gn % 32 == 0 and c_gn <= 1280):
+            f32_form = (self.dtype == torch.float32 and not pw.split and geom_ok and ln_in is None and a2 is None
+                        and (conv is None or pw.n <= self.fuse_gn_conv_max_n)
+                        and (conv is not None) == bool(gn_in["silu"]) and c_gn % 32 == 0 and c_gn <= 1280)
+            # bf16: the row-panel tiles normalise the rows they keep in registers (affine only, i.e. the projection
+            # behind an AttentionBlock's GroupNorm); whether the launch gets such a tile is known once it is chosen
+            panel_form = (self.dtype == torch.bfloat16 and conv is None and not gn_in["silu"] and ln_in is None
+                          and a2 is None and c_gn in (320, 640))
+            if self.fuse_gn_apply and (f32_form or panel_form):
                 gn_rec = self._gn_lookup(a, gn_in["batch"], gn_in.get("groups", 32))
             if gn_rec is None:
                 a = self._gn_unfused(a, gn_in)
@@ -473,8 +477,9 @@ class Engine:
             if pw.split:
                 key = key + ("w_split" if pw.split == 2 else "w_split3",)  # other kernels, other winners
             if gn_rec is not None:
-                # the fragment-side GroupNorm changes the LDS footprint and the loop: its own entry
-                key = key + ("gn_in",)
+                if self.dtype == torch.float32:
+                    # the fragment-side GroupNorm changes the LDS footprint and the loop: its own entry
+                    key = key + ("gn_in",)
                 self._bind_gn(d, gn_rec, gn_in)
             best = self.tuned.get(key)
             if best is None and self.autotune and not self.arena.frozen and self.profile is None:
@@ -490,7 +495,12 @@ class Engine:
         if gn_rec is not None:
             if self.tile_override is not None:
                 self._bind_gn(d, gn_rec, gn_in)
-            if not self.lib.dm_gemm_gn_supported(self.dm, tile.value, d.conv, a.shape[1], d.gn_groups, gn_in["hw"], sk.value):
+            if tile.value in _lib.PANEL_TILES:
+                fused_ok = self.lib.dm_gemm_panel_supported(C.byref(d), tile.value, max(sk.value, 1))
+            else:
+                fused_ok = self.dtype == torch.float32 and self.lib.dm_gemm_gn_supported(
+                    self.dm, tile.value, d.conv, a.shape[1], d.gn_groups, gn_in["hw"], sk.value)
+            if not fused_ok:
                 # the chosen tile has no fragment-side form for this shape: normalise with the stand-alone kernel
                 a = self._gn_unfused(a, gn_in)
                 d.a, d.lda = a.data_ptr(), a.stride(0)

@@ -764,3 +764,42 @@ def test_gemm_panel_refused_where_unsupported(dev):
                 eng.gemm(torch.zeros(128, k, dtype=dt, device=dev), pw)
         finally:
             eng.tile_override = None
+
+
+@pytest.mark.parametrize("tile", PANEL)
+@pytest.mark.parametrize("ns", [1, 2])
+@pytest.mark.parametrize("c", [320, 640])
+def test_gemm_panel_groupnorm_of_the_operand(dev, tile, ns, c):
+    """bf16: the GroupNorm in front of an AttentionBlock's input projection (blocks.py:128-129, no activation) applied by the
+    row-panel launch to the rows it keeps in registers, from the per-group sums the producing launch accumulated; the
+    normalised tensor is never written.  Three samples, so blocks of different samples use different statistics."""
+    eng = _bf16_engine(dev)
+    if tile == _lib.TILE_P128 and c != 320:
+        pytest.skip("P128 exists for K = 320")
+    b, hw, k0, n = 3, 256, 64, c
+    m = b * hw
+    a0 = tin("pg.a0", (m, k0)) * (1 + torch.arange(m)[:, None] // hw); w0 = tin("pg.w0", (c, k0), scale=1 / math.sqrt(k0))
+    b0 = tin("pg.b0", (c,)) + 0.3
+    gamma = tin("pg.g", (c,)) + 1; beta = tin("pg.be", (c,)) * 0.5
+    lin0 = torch.nn.Linear(k0, c); lin1 = torch.nn.Linear(c, n)
+    w1 = tin("pg.w1", (n, c), scale=1 / math.sqrt(c)); b1 = tin("pg.b1", (n,))
+    with torch.no_grad():
+        lin0.weight.copy_(w0); lin0.bias.copy_(b0); lin1.weight.copy_(w1); lin1.bias.copy_(b1)
+    x = eng.gemm(up(eng, a0), eng.pack_linear(lin0), gn_batch=b)  # producer: writes x and its per-group sums
+    assert eng._gn_lookup(x, b) is not None
+    gn = dict(batch=b, hw=hw, gamma=gamma.to(dev), beta=beta.to(dev), eps=1e-6, silu=False)
+
+    def no_fallback(*_):
+        raise AssertionError("the panel launch did not normalise its operand (fell back to the GroupNorm kernel)")
+
+    eng._gn_unfused = no_fallback
+    eng.tile_override = (tile, ns)
+    try:
+        out = eng.gemm(x, eng.pack_linear(lin1), gn_in=gn, ln_out=True)
+    finally:
+        eng.tile_override = None
+        del eng._gn_unfused
+    xs = x.float().cpu()
+    xn = F.group_norm(xs.reshape(b, hw, c).permute(0, 2, 1), 32, gamma, beta, eps=1e-6).permute(0, 2, 1).reshape(m, c)
+    ref = rnd(xn, eng.dtype) @ rnd(w1, eng.dtype).t() + b1
+    assert max_rel(out.float(), ref) < BF16_TOL
