@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(ROOT, "diffusion_model_amd", "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libdm_hip.so")
-SOURCES = ["gemm.hip", "panel.hip", "attention.hip", "norm.hip", "elementwise.hip"]
+SOURCES = ["gemm.hip", "panel.hip", "ffn.hip", "attention.hip", "norm.hip", "elementwise.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "panel.h"), os.path.join(ROOT, "include", "dm_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include")]
 

@@ -69,6 +69,22 @@ class GemmDesc(C.Structure):
     ]
 
 
+class FfnDesc(C.Structure):
+    """DmFfnDesc: the feed-forward half of an AttentionBlock as one launch (dm_ffn_geglu)."""
+    _fields_ = [
+        ("a", C.c_void_p), ("lda", C.c_long),
+        ("w1", C.c_void_p), ("bias1", C.c_void_p),
+        ("ln_in", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
+        ("w2", C.c_void_p), ("bias2", C.c_void_p), ("npad2", C.c_int),
+        ("r", C.c_void_p), ("ldr", C.c_long),
+        ("c", C.c_void_p), ("ldc", C.c_long),
+        ("m", C.c_int), ("c_model", C.c_int), ("dtype", C.c_int),
+        ("rows_per_batch", C.c_int),
+        ("stats", C.c_void_p), ("ld_stats", C.c_long), ("stats_cpg", C.c_int), ("stats_ch0", C.c_int),
+        ("stats2", C.c_void_p), ("ld_stats2", C.c_long), ("stats2_cpg", C.c_int), ("stats2_ch0", C.c_int),
+    ]
+
+
 _vp, _l, _i, _f = C.c_void_p, C.c_long, C.c_int, C.c_float
 _PROTOS = {
     "dm_abi_version": (C.c_int, []),
@@ -79,6 +95,8 @@ _PROTOS = {
     "dm_gemm_stats_supported": (C.c_int, [_i, _i, _i]),
     "dm_gemm_panel_supported": (C.c_int, [C.POINTER(GemmDesc), _i, _i]),
     "dm_gemm_gn_supported": (C.c_int, [_i, _i, _i, _i, _i, _i, _i]),
+    "dm_ffn_geglu": (C.c_int, [C.POINTER(FfnDesc), _vp]),
+    "dm_ffn_geglu_supported": (C.c_int, [_i, _i, _i, _i, _i]),
     "dm_groupnorm_apply_sums": (C.c_int, [_vp, _l, _vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _f, _i, _vp]),
     "dm_zero": (C.c_int, [_vp, _l, _vp]),
     "dm_pack_weight_order": (C.c_int, [_i, _i, _i, _vp]),
@@ -142,7 +160,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dm_abi_version() != 10:
+        if handle.dm_abi_version() != 11:
             raise RuntimeError("libdm_hip.so ABI version mismatch; rebuild with `python build.py`")
         _lib = handle
     return _lib

@@ -136,6 +136,8 @@ class Engine:
         self.fuse_skip = os.environ.get("DM_FUSE_SKIP", "1") != "0"  # residual_layer folded into the second conv
         self.fuse_tail = os.environ.get("DM_FUSE_TAIL", "1") != "0"  # linear_geglu_2 + residue + conv_output as one GEMM
         self.fuse_gn_stats = os.environ.get("DM_FUSE_GN_STATS", "1") == "1"
+        # bf16, C = 320: linear_geglu_1 -> GELU gate -> [linear_geglu_2 + residue -> conv_output] as one launch
+        self.fuse_ffn = os.environ.get("DM_FUSE_FFN", "1") != "0"
         # fp32: GroupNorm (+ SiLU) applied to the A fragments of the convolution / projection that reads it
         self.fuse_gn_apply = os.environ.get("DM_FUSE_GN_APPLY", "1") != "0"
         # ... for convolutions only up to this many output channels.  The map is redone by every block that reads the
@@ -524,27 +526,65 @@ class Engine:
         elif sk.value < 0:
             self._bind_streamk(d, tile.value, m, pw.n, -sk.value)
         if gn_batch > 0 and self.fuse_gn_stats and nchw_out is None and not pw.geglu:
-            targets = self._gn_targets(out, gn_batch)
             hw = m // gn_batch
             ok = (m % gn_batch == 0 and (rows_per_batch in (0, hw)) and tile.value != _lib.TILE_AUTO
                   and self.lib.dm_gemm_stats_supported(tile.value, hw, sk.value))
-            live = [(rec, off) for rec, off in targets if ok and rec["valid"]]
-            for rec, off in targets:
-                if (rec, off) in live:
-                    rec["parts"] += n_out
-                else:
-                    rec["valid"] = False
-            if live:
-                d.rows_per_batch = hw
-                (r1, o1) = live[0]
-                d.stats, d.ld_stats, d.stats_cpg, d.stats_ch0 = r1["stats"].data_ptr(), r1["groups"], r1["cpg"], o1
-                if len(live) > 1:
-                    (r2, o2) = live[1]
-                    d.stats2, d.ld_stats2, d.stats2_cpg, d.stats2_ch0 = r2["stats"].data_ptr(), r2["groups"], r2["cpg"], o2
+            self._bind_out_stats(d, out, gn_batch, hw, n_out, ok)
         with self._prof(klass, 2.0 * m * pw.n * (pw.k if conv is None else 9 * conv["cin_real"] + pw.skip_cin),
                         f"m={m} n={pw.n} k={pw.k} tile={tile.value} sk={sk.value} epi={d.epi}"
                         + (f" s={d.stride} up={d.up}" if conv is not None else "")):
             check(self.lib.dm_gemm(C.byref(d), self.stream), klass)
+        return out
+
+    def _bind_out_stats(self, d, out: torch.Tensor, gn_batch: int, hw: int, n_out: int, ok: bool):
+        """A GroupNorm over ``gn_batch`` samples reads ``out`` next: point the launch descriptor ``d`` at the per-group
+        sums it accumulates (the tensor's own, and those of the concatenation buffer it is a slice of), or - when the
+        launch cannot produce them (``ok`` false) - mark the records incomplete so that a statistics pass runs."""
+        targets = self._gn_targets(out, gn_batch)
+        live = [(rec, off) for rec, off in targets if ok and rec["valid"]]
+        for rec, off in targets:
+            if (rec, off) in live:
+                rec["parts"] += n_out
+            else:
+                rec["valid"] = False
+        if live:
+            d.rows_per_batch = hw
+            (r1, o1) = live[0]
+            d.stats, d.ld_stats, d.stats_cpg, d.stats_ch0 = r1["stats"].data_ptr(), r1["groups"], r1["cpg"], o1
+            if len(live) > 1:
+                (r2, o2) = live[1]
+                d.stats2, d.ld_stats2, d.stats2_cpg, d.stats2_ch0 = r2["stats"].data_ptr(), r2["groups"], r2["cpg"], o2
+
+    def ffn_ok(self, m: int, c: int, batch: int) -> bool:
+        """Whether the feed-forward half of an AttentionBlock over ``m`` rows of width ``c`` runs as one launch."""
+        return bool(self.fuse_ffn and batch > 0 and m % batch == 0
+                    and self.lib.dm_ffn_geglu_supported(self.dm, m, c, m // batch, 1))
+
+    def ffn_geglu(self, t: torch.Tensor, pw1: PackedWeight, pw2: PackedWeight, out: torch.Tensor, *,
+                  residual: Optional[torch.Tensor], ln_in: torch.Tensor, gn_batch: int = 0) -> torch.Tensor:
+        """``conv_output(linear_geglu_2(v * gelu(g)) + t) + residual`` with ``[v | g] = linear_geglu_1(LN(t))`` as one
+        launch (dm_ffn_geglu): ``pw1`` = linear_geglu_1 packed with the GEGLU interleave and its LayerNorm
+        (``pack_linear(..., geglu=True, ln=...)``), ``pw2`` = ``pack_chain(linear_geglu_2, conv_output)``, ``ln_in`` the row
+        sums of ``t``.  The 4C-wide product never reaches memory."""
+        m, c = t.shape
+        if not (pw1.geglu and pw1.colsum is not None and pw1.k == c and pw1.n == 8 * c and pw2.skip_cin == c
+                and pw2.k == 5 * c and pw2.n == c and out.shape == (m, c)):
+            raise RuntimeError("feed-forward operands do not match (linear_geglu_1 with its LayerNorm, chained tail)")
+        d = _lib.FfnDesc()
+        d.a, d.lda = t.data_ptr(), t.stride(0)
+        d.w1, d.bias1 = pw1.w.data_ptr(), pw1.bias.data_ptr()
+        d.ln_in, d.ln_colsum, d.ln_eps = ln_in.data_ptr(), pw1.colsum.data_ptr(), pw1.ln_eps
+        d.w2, d.bias2, d.npad2 = pw2.w.data_ptr(), pw2.bias.data_ptr(), pw2.npad
+        if residual is not None:
+            d.r, d.ldr = residual.data_ptr(), residual.stride(0)
+        d.c, d.ldc = out.data_ptr(), out.stride(0)
+        d.m, d.c_model, d.dtype = m, c, self.dm
+        if gn_batch > 0 and self.fuse_gn_stats:
+            hw = m // gn_batch
+            ok = m % gn_batch == 0 and bool(self.lib.dm_ffn_geglu_supported(self.dm, m, c, hw, 1))
+            self._bind_out_stats(d, out, gn_batch, hw, c, ok)
+        with self._prof("gemm", 2.0 * m * (pw1.n * pw1.k + pw2.n * pw2.k), f"m={m} c={c} ffn (geglu_1 + tail)"):
+            check(self.lib.dm_ffn_geglu(C.byref(d), self.stream), "ffn_geglu")
         return out
 
     @staticmethod

@@ -224,6 +224,11 @@ def run_attention_block(eng: Engine, pk: NS, x, batch: int, h: int, w: int, kv, 
         t = eng.gemm(x, pk.conv_in, ln_out=True, gn_in=gn)
         t = run_self_attention(eng, pk.sa, t, batch, s, residual=t, ln_in=eng.ln_stats(t), ln_out=True)
         t = run_cross_attention(eng, pk.ca, t, kv, batch, s, sk, residual=t, ln_in=eng.ln_stats(t), ln_out=True)
+        if pk.tail is not None and eng.ffn_ok(batch * s, pk.c, batch):
+            # the whole feed-forward half in one launch: the 4C-wide gated product stays on the CU
+            eng.ffn_geglu(t, pk.geglu1, pk.tail, out, residual=x, ln_in=eng.ln_stats(t), gn_batch=batch)
+            eng.arena.release(mark)
+            return out
         a = eng.gemm(t, pk.geglu1, ln_in=eng.ln_stats(t))
     else:
         t = eng.gemm(x, pk.conv_in, gn_in=gn)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 10
+#define DM_ABI_VERSION 11
 
 #define DM_F32 0
 #define DM_BF16 1
@@ -193,6 +193,29 @@ long dm_gemm_streamk_workspace_bytes(int tile, int m, int n, int blocks);
 int dm_gemm_stats_supported(int tile, int rows_per_batch, int splitk);
 /* 1 when the descriptor's problem can run on the row-panel tile `tile` (DM_TILE_P*) with `nsplit` column slices. */
 int dm_gemm_panel_supported(const DmGemmDesc* d, int tile, int nsplit);
+/* Feed-forward half of an AttentionBlock as one launch (bf16, C = 320):
+ *   out = conv_output(linear_geglu_2(v * gelu(g)) + t) + x,  [v | g] = linear_geglu_1(layernorm_3(t))
+ * replaces /root/reference/src/models/blocks.py:137-153 (layernorm_3, linear_geglu_1, the GELU gate, linear_geglu_2, the
+ * residue add, conv_output and the long residue).  The 4C-wide product stays on the CU.  Operands are the ones the two
+ * dm_gemm calls of the unfused form take: w1 = linear_geglu_1 packed with the GEGLU row interleave and the LayerNorm folded
+ * in (bias1, ln_colsum; ln_in = per-row (sum, sumsq) of t), w2 = the matrix [W_c W_2 | W_c] over the row [product | t]
+ * packed as a dm_gemm weight image of npad2 x 5C (bias2 = W_c b_2 + b_c), r = the block input x (may be NULL).
+ * m must be a multiple of 128; with statistics (stats / stats2 as in DmGemmDesc) rows_per_batch must be a multiple of 128. */
+typedef struct DmFfnDesc {
+    const void* a; long lda;
+    const void* w1; const float* bias1;
+    const double* ln_in; const float* ln_colsum; float ln_eps;
+    const void* w2; const float* bias2; int npad2;
+    const void* r; long ldr;
+    void* c; long ldc;
+    int m, c_model, dtype;
+    int rows_per_batch;
+    double* stats; long ld_stats; int stats_cpg, stats_ch0;
+    double* stats2; long ld_stats2; int stats2_cpg, stats2_ch0;
+} DmFfnDesc;
+int dm_ffn_geglu(const DmFfnDesc* d, hipStream_t stream);
+/* 1 when dm_ffn_geglu takes a problem of this shape */
+int dm_ffn_geglu_supported(int dtype, int m, int c_model, int rows_per_batch, int want_stats);
 /* 1 when DmGemmDesc.gn_sums may be used with this tile: C = channels that are normalised (see above). */
 int dm_gemm_gn_supported(int dtype, int tile, int conv, int c, int groups, int rows_per_batch, int splitk);
 /* order[p] = source weight row of packed row p (or -1 for a zero row), for p in [0, npad). */

@@ -803,3 +803,63 @@ def test_gemm_panel_groupnorm_of_the_operand(dev, tile, ns, c):
     xn = F.group_norm(xs.reshape(b, hw, c).permute(0, 2, 1), 32, gamma, beta, eps=1e-6).permute(0, 2, 1).reshape(m, c)
     ref = rnd(xn, eng.dtype) @ rnd(w1, eng.dtype).t() + b1
     assert max_rel(out.float(), ref) < BF16_TOL
+
+
+# ------------------------------------------------------------------------------------------- fused feed-forward
+@pytest.mark.parametrize("batch,hw", [(1, 128), (3, 256), (2, 1024)])
+@pytest.mark.parametrize("with_x", [True, False])
+def test_ffn_geglu_one_launch(dev, batch, hw, with_x):
+    """The feed-forward half of an AttentionBlock (blocks.py:137-153: layernorm_3, linear_geglu_1, GELU gate, linear_geglu_2,
+    residue, conv_output, long residue) as one launch against fp32 torch math on the CPU and against the two-launch form of
+    the same packed operands; the per-group sums of the output feed a GroupNorm.  Several samples, so blocks of different
+    samples add into different statistics rows; the output lands in a channel slice of a wider buffer."""
+    eng = _bf16_engine(dev)
+    c, m = 320, batch * hw
+    k0 = 64
+    a0 = tin("ff.a0", (m, k0)); w0 = tin("ff.w0", (c, k0), scale=1 / math.sqrt(k0)); b0 = tin("ff.b0", (c,)) + 0.4
+    x = tin("ff.x", (m, c)) * (1 + torch.arange(m)[:, None] // hw)
+    gamma = tin("ff.g", (c,)) + 1; beta = tin("ff.be", (c,)) * 0.5
+    w1 = tin("ff.w1", (8 * c, c), scale=1 / math.sqrt(c)); b1 = tin("ff.b1", (8 * c,))
+    w2 = tin("ff.w2", (c, 4 * c), scale=1 / math.sqrt(4 * c)); b2 = tin("ff.b2", (c,))
+    wc = tin("ff.wc", (c, c), scale=1 / math.sqrt(c)); bc = tin("ff.bc", (c,))
+    gn_g = tin("ff.gg", (c,)) + 1; gn_b = tin("ff.gb", (c,))
+    l0 = torch.nn.Linear(k0, c); l1 = torch.nn.Linear(c, 8 * c); l2 = torch.nn.Linear(4 * c, c)
+    ln = torch.nn.LayerNorm(c, eps=1e-5); co = torch.nn.Conv2d(c, c, 1)
+    with torch.no_grad():
+        l0.weight.copy_(w0); l0.bias.copy_(b0); l1.weight.copy_(w1); l1.bias.copy_(b1); l2.weight.copy_(w2); l2.bias.copy_(b2)
+        ln.weight.copy_(gamma); ln.bias.copy_(beta); co.weight.copy_(wc.reshape(c, c, 1, 1)); co.bias.copy_(bc)
+    p0 = eng.pack_linear(l0); p1 = eng.pack_linear(l1, geglu=True, ln=ln); p2 = eng.pack_chain(l2, co)
+    assert eng.ffn_ok(m, c, batch)
+    t = eng.gemm(up(eng, a0), p0, ln_out=True)  # the residual stream and its row sums
+    xd = up(eng, x) if with_x else None
+    wide = eng.new(m, c + 64)
+    wide.zero_()
+    out = wide[:, 32:32 + c]
+    eng.ffn_geglu(t, p1, p2, out, residual=xd, ln_in=eng.ln_stats(t), gn_batch=batch)
+    assert eng._gn_lookup(out, batch) is not None, "the launch did not accumulate the statistics of its output"
+    y = eng.groupnorm(out, batch, hw, gn_g.to(dev), gn_b.to(dev), 1e-5, silu=True)
+    assert float(wide[:, :32].abs().max()) == 0.0 and float(wide[:, 32 + c:].abs().max()) == 0.0
+    # two-launch form on the same operands
+    g2 = eng.gemm(t, p1, ln_in=eng.ln_stats(t))
+    ref2 = eng.gemm(g2, p2, a2=t, residual=xd)
+    assert max_rel(out.float(), ref2.float()) < 1e-2
+    # fp32 math of the reference's operator chain on the stored residual stream
+    ts = t.float().cpu()
+    v, g = F.linear(F.layer_norm(ts, (c,), gamma, beta, 1e-5), w1, b1).chunk(2, dim=-1)
+    ref = F.linear(F.linear(v * F.gelu(g), w2, b2) + ts, wc, bc)
+    if with_x:
+        ref = ref + rnd(x, eng.dtype)
+    assert max_rel(out.float(), ref) < 3e-2
+    os_ = out.float().cpu()
+    gref = F.silu(F.group_norm(os_.reshape(batch, hw, c).permute(0, 2, 1), 32, gn_g, gn_b, 1e-5)).permute(0, 2, 1).reshape(m, c)
+    assert max_rel(y.float(), gref) < BF16_TOL
+
+
+def test_ffn_geglu_refused_where_unsupported(dev):
+    """One launch exists for bf16, C = 320 and whole blocks of 128 rows inside one sample; everything else reports so and the
+    block runner keeps the two-launch form."""
+    eng = _bf16_engine(dev)
+    assert not eng.ffn_ok(4096, 640, 1) and not eng.ffn_ok(4096 + 64, 320, 1) and not eng.ffn_ok(3 * 192, 320, 3)
+    assert not Engine.get(dev, torch.float32).ffn_ok(4096, 320, 1)
+    d = _lib.FfnDesc()
+    assert _lib.lib().dm_ffn_geglu(d, None) != 0

@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/dm_hip.h but not exported"
     assert sorted(_lib.EXPORTED_SYMBOLS) == names, "ctypes prototypes and header are out of sync"
-    assert handle.dm_abi_version() == 9
+    header = open(os.path.join(ROOT, "include", "dm_hip.h")).read()
+    assert handle.dm_abi_version() == int(re.search(r"#define DM_ABI_VERSION (\d+)", header).group(1))
 
 
 def test_pack_order_is_a_permutation_with_lane_contiguous_columns():
