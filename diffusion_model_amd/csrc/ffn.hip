@@ -11,24 +11,40 @@
 //   * a block owns 128 rows; wave (pr, h) of its 8 waves holds the rows 32 pr .. 32 pr + 31 of t in registers for the whole
 //     launch, as MFMA fragments (C = 320: 2 x 10 fragments), and accumulates HALF of the block's 128 x C output tile for them:
 //     the 16-column tiles 2h, 2h + 1 of every 64-column group (2 x 10 accumulator tiles);
-//   * the weights stream through an LDS ring of 8 KiB slots (one k-tile of one 64-row group of an image) by LDS-DMA, in the
-//     order of use: per pair of column tiles (2q, 2q + 1) of the first product 2 x KT slots of W1, then the k-tile q of W2 for
-//     each of its C / 64 row groups; behind all pairs the k-tiles of W2 that multiply t itself.  Every slot is one barrier,
-//     four fragment reads and eight MFMAs per wave, whatever it belongs to, and each fragment read feeds two MFMAs;
+//   * the weights stream through LDS in 8 KiB slots (one k-tile of one 64-row group of an image) by LDS-DMA, in the order of
+//     use (SlotOrder below).  Every slot is four fragment reads and eight MFMAs per wave, whatever it belongs to, and each
+//     fragment read feeds two MFMAs.  The stream is cut into PHASES of KT = 5 slots - the k-tiles of one column tile of the
+//     first product, or the C / 64 row groups of one k-tile of the second - and the ring is two phases long.  A phase passes
+//     two barriers (slots 0-2, slots 3-4) instead of one per slot: a wave can issue one instruction every four cycles, two
+//     waves share a SIMD, and at eight MFMAs per barrier the waits, scalar bookkeeping and slot requests around them, not
+//     the matrix pipe, set the pace;
 //   * of a 64-row slot of W1 (16 value columns and their 16 gates per 16-row tile pair) wave half h takes value tile h and
 //     gate tile 2 + h, so that every lane holds values and gates of the same four product columns; bias, folded LayerNorm,
-//     erf-GELU and the product happen in registers and give, per lane, four bf16 products of columns 32 jt + 8 fq + 4 h + r;
+//     erf-GELU and the product happen in registers and give, per lane, four bf16 products of columns 32 jt + 8 fq + 4 h + r.
+//     This epilogue is cut into four quarters that run one per slot behind the MFMAs of the NEXT phase, on accumulators those
+//     MFMAs do not touch, so the VALU work overlaps the matrix pipe instead of waiting for it (the second product of a pair of
+//     column tiles therefore runs one pair late);
 //   * the second product needs all eight products 32 jt + 8 fq + 0..7 of a lane group as its k operand: the two halves of a
 //     wave pair swap their four through LDS (8 bytes per lane and row tile), which is the only exchange between waves;
 //   * the main loop contains no vector-memory instruction other than the slot requests, so the counted s_waitcnt vmcnt(N) on
-//     them is exact and nothing the block stores ever delays an operand.
+//     them is exact and nothing the block stores ever delays an operand; it contains no branch either (slot addresses come
+//     from a constant table by scalar loads one phase ahead).
 // The epilogue adds bias and the long residual x, stores bf16, and reduces the per-column sums of the stored values over the
 // block's rows (in-wave butterfly, then a fixed-order sum over the four row groups through LDS) to the per-group statistics
 // the next GroupNorm reads.
+#include <type_traits>
+
 #include "common.h"
 #include "dm_hip.h"
 
 namespace {
+
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 struct FfnArgs {
     const char* A;
@@ -54,26 +70,46 @@ constexpr int SLOT = 64 * 128;  // bytes: one k-tile (64 bf16) of one 64-row gro
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// at most min(young, MAXY) slot requests (one instruction each) may still be outstanding
-template <int MAXY> __device__ __forceinline__ void wait_young(int young) {
-    if constexpr (MAXY == 0) {
-        wait_vm<0>();
-    } else {
-        if (young >= MAXY) wait_vm<MAXY>();
-        else wait_young<MAXY - 1>(young);
-    }
-}
 
-template <int KT, int STAGES>
+// Order of the weight slots, in phases of KT: W1 of pair 0 (column tiles 0 and 1: two phases); for q = 1 .. NP-1 the two
+// phases of W1 of pair q (column tiles 2q, 2q + 1), then the phase of k-tile q - 1 of W2 (one slot per 64-row group); the
+// phase of k-tile NP - 1 of W2; the KT phases of the k-tiles of W2 that multiply t.  An entry is the slot's index inside its
+// blocked image [rows / 64][k-tiles][64][128 B]; bit 30 marks the second image.
+template <int KT> struct SlotOrder {
+    static constexpr int NP = 4 * KT, G2 = KT, NKT2 = 5 * KT, T = NP * 3 * KT + KT * G2;
+    struct Tab {
+        int v[T + 8];  // padded: the entries of a phase's requests are read as one window of KT, also near the end
+    };
+    static constexpr Tab make() {
+        Tab t{};
+        int n = 0;
+        for (int q = 0; q < NP; ++q) {
+            for (int r = 0; r < 2 * KT; ++r) t.v[n++] = q * 2 * KT + r;
+            if (q > 0)
+                for (int g = 0; g < G2; ++g) t.v[n++] = (1 << 30) | (g * NKT2 + q - 1);
+        }
+        for (int g = 0; g < G2; ++g) t.v[n++] = (1 << 30) | (g * NKT2 + NP - 1);
+        for (int kt = 0; kt < KT; ++kt)
+            for (int g = 0; g < G2; ++g) t.v[n++] = (1 << 30) | (g * NKT2 + 4 * KT + kt);
+        return t;
+    }
+    __device__ static const int* table();
+};
+__device__ const SlotOrder<5>::Tab g_slot_order_5 = SlotOrder<5>::make();
+template <> __device__ __forceinline__ const int* SlotOrder<5>::table() { return g_slot_order_5.v; }
+
+template <int KT>
 __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(FfnArgs p) {
+    static_assert(KT == 5, "the two barrier groups of a phase are slots 0-2 and 3-4");
     constexpr int C = KT * 64;            // width of the residual stream
     constexpr int NJT = 8 * KT;           // 64-row column tiles of W1 (8C packed rows: 4C values interleaved with 4C gates)
     constexpr int NP = NJT / 2;           // pairs of them = k-tiles of the product part of W2
     constexpr int G2 = KT;                // 64-column groups of the output
-    constexpr int NKT2 = 5 * KT;          // k-tiles of W2: 4C product columns, then C columns of t
-    constexpr int PAIR = 2 * KT + G2;     // slots per pair
-    constexpr int T = NP * PAIR + KT * G2;
-    static_assert(STAGES >= 3 && STAGES - 2 <= 63, "ring depth / vmcnt field");
+    constexpr int T = SlotOrder<KT>::T;   // slots in all
+    constexpr int NPH = T / KT;           // phases
+    constexpr int HALF = KT * SLOT;       // bytes of one half of the ring = one phase
+    using True = std::true_type;
+    using False = std::false_type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -87,33 +123,29 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(FfnArgs p) {
     // the fragment reads conflict-free is applied to the SOURCE chunk (the DMA writes LDS lane-linearly).
     const int my_off = (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) << 4);
     char* const ldst = smem + wave * 1024;
-    auto slot_src = [&](int s) -> const char* {
-        if (s < NP * PAIR) {
-            const int q = s / PAIR, r = s - q * PAIR;
-            if (r < 2 * KT) return p.W1 + (long)(q * 2 * KT + r) * SLOT;
-            return p.W2 + (long)((r - 2 * KT) * NKT2 + q) * SLOT;
-        }
-        const int u = s - NP * PAIR;
-        const int kt = u / G2, g = u - kt * G2;
-        return p.W2 + (long)(g * NKT2 + 4 * KT + kt) * SLOT;
+    const int* const order = SlotOrder<KT>::table();
+    auto issue = [&](int entry, int lds_off) __attribute__((always_inline)) {
+        const char* base = (entry & (1 << 30)) ? p.W2 : p.W1;
+        base += (long)(entry & 0xffffff) * SLOT;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (unsigned)my_off),
+                                         (__attribute__((address_space(3))) void*)(ldst + lds_off), 16, 0, 0);
     };
-    auto issue = [&](int s, int stage) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slot_src(s) + my_off),
-                                         (__attribute__((address_space(3))) void*)(ldst + stage * SLOT), 16, 0, 0);
-    };
+    // phase 0 whole and the first barrier group of phase 1
 #pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s) issue(s, s);
+    for (int s = 0; s < KT + 3; ++s) issue(order[s], s * SLOT);
 
     // ---- column terms of the first product, behind the ring, in the order its epilogue reads them: per column tile 64 bias
     // floats [fq][8 value biases | their 8 gate biases] and the 64 column sums [fq][j][4] of the folded LayerNorm
-    float* const tab = reinterpret_cast<float*>(smem + STAGES * SLOT);
+    float* const tab = reinterpret_cast<float*>(smem + 2 * HALF);
     for (int idx = tid; idx < NJT * 64; idx += 512) {
         const int jl = idx >> 6, q = (idx >> 4) & 3, e = idx & 15;
         const int n0t = jl * 64;
         tab[jl * 128 + q * 16 + e] = p.bias1[(e < 8 ? 0 : NJT * 32) + (n0t >> 1) + q * 8 + (e & 7)];
         tab[jl * 128 + 64 + q * 16 + e] = p.ln_colsum[n0t + 16 * (e >> 2) + 4 * q + (e & 3)];
     }
-    // exchange buffer of the product halves: [row group][column-tile parity][row tile][lane][16 B], wave half h owns bytes 8h .. 8h + 7
+    // exchange buffers of the product halves, one per pair parity: [row group][column-tile parity][row tile][lane][16 B], wave
+    // half h owns bytes 8h .. 8h + 7
+    constexpr int PBUF = 4 * 2 * 2 * 64 * 16;
     char* const pbuf = reinterpret_cast<char*>(tab + NJT * 128);
 
     // ---- the wave's rows of t, once, into registers: fragment (i, ks) of lane (fr, fq) = row mrow0 + 16 i + fr, k = 32 ks + 8 fq .. + 8
@@ -141,92 +173,131 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(FfnArgs p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) oacc[g][jj][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int t = 0, stage = 0;
-    // Start of slot t: it has landed once only the younger requests (at most STAGES-2) are outstanding; the barrier makes every
-    // wave's share visible, retires all reads of the slot refilled right after it, and publishes LDS writes made before it.
-    auto slot_begin = [&]() -> const char* {
-        wait_young<STAGES - 2>(T - 1 - t);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + STAGES - 1 < T) {
-            int ns = stage + STAGES - 1;
-            if (ns >= STAGES) ns -= STAGES;
-            issue(t + STAGES - 1, ns);
-        }
-        const char* sw = smem + stage * SLOT;
-        ++t;
-        if (++stage == STAGES) stage = 0;
-        return sw;
-    };
-    // fragments of the wave's two 16-row tiles j0, j1 of a slot, both k-steps
-    auto read_w = [&](const char* sw, int j0, int j1, u32x4 (&w)[2][2]) {
+    // ---- one phase.  Its slots sit in half (ph & 1) of the ring.  Requests in flight, in order, when its first barrier
+    // group starts: the phase's five slots and slots 0-2 of the next phase; slots 0-2 have landed once at most Y0 = 5 requests
+    // are outstanding.  Behind that barrier every wave is done with the previous phase, whose slots 3-4 (other half) are
+    // refilled with slots 3-4 of the next phase; behind the second barrier (slots 3-4 landed: again at most 5 outstanding)
+    // slots 0-2 of this half are refilled with those of the phase after next.  Each barrier follows a wait for the wave's
+    // own LDS reads and publishes LDS writes made before it.  e[]: table entries of the five slots this phase requests,
+    // loaded one phase ahead.
+    int ph = 0;
+    int e[KT];
+#pragma unroll
+    for (int i = 0; i < KT; ++i) e[i] = order[KT + 3 + i];
+    auto rd = [&](const char* sw, u32x4 (&dst)[2][2], int j0, int j1) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            w[ks][0] = *reinterpret_cast<const u32x4*>(sw + swz(j0 * 16 + fr, ks * 4 + fq));
-            w[ks][1] = *reinterpret_cast<const u32x4*>(sw + swz(j1 * 16 + fr, ks * 4 + fq));
+            dst[ks][0] = *reinterpret_cast<const u32x4*>(sw + swz(j0 * 16 + fr, ks * 4 + fq));
+            dst[ks][1] = *reinterpret_cast<const u32x4*>(sw + swz(j1 * 16 + fr, ks * 4 + fq));
         }
     };
-
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the table writes above; the first barrier publishes them
-    for (int q = 0; q < NP; ++q) {
-        // ---- first product for column tiles 2q and 2q + 1, each followed by its GEGLU epilogue
-#pragma unroll
-        for (int par = 0; par < 2; ++par) {
-            f32x4 acc[2][2];  // [value | gate][row tile]
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[jj][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                const char* sw = slot_begin();
-                u32x4 w[2][2];
-                read_w(sw, h, 2 + h, w);
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        Mma16<bf16_t>::mma(acc[0][i], w[ks][0], afr[i][2 * kt + ks]);
-                        Mma16<bf16_t>::mma(acc[1][i], w[ks][1], afr[i][2 * kt + ks]);
-                    }
-            }
-            // lane holds, for rows mrow0 + 16 i + fr, the values of product columns 32 jt + 8 fq + 4 h + r and their gates
-            const float* const tb = tab + (2 * q + par) * 128 + fq * 16;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(tb + 4 * h);
-            const f32x4 bg = *reinterpret_cast<const f32x4*>(tb + 8 + 4 * h);
-            const f32x4 cv = *reinterpret_cast<const f32x4*>(tb + 64 + 4 * h);
-            const f32x4 cg = *reinterpret_cast<const f32x4*>(tb + 64 + 4 * (2 + h));
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                float o[4];
-#pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    // LN(a) W^T = rstd * (a W'^T - mean * colsum(W')) + (beta W^T + b); two values per packed instruction
-                    const f32x2 mu = {ln_mu[i], ln_mu[i]}, rs = {ln_rs[i], ln_rs[i]};
-                    const f32x2 gv = rs * (f32x2{acc[1][i][r], acc[1][i][r + 1]} - mu * f32x2{cg[r], cg[r + 1]}) + f32x2{bg[r], bg[r + 1]};
-                    const f32x2 vv = rs * (f32x2{acc[0][i][r], acc[0][i][r + 1]} - mu * f32x2{cv[r], cv[r + 1]}) + f32x2{bv[r], bv[r + 1]};
-                    const f32x2 pv = vv * gelu_erf_fast_f2(gv);
-                    o[r] = pv[0];
-                    o[r + 1] = pv[1];
-                }
-                *reinterpret_cast<u32x2*>(pbuf + ((((pr * 2 + par) * 2 + i) * 64 + lane) << 4) + 8 * h) =
-                    u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-            }
+    // j0, j1: the wave's two 16-row tiles in every slot of the phase; mm(k_, fragments): the MFMAs of slot k; side(k_): VALU
+    // work placed behind them
+    // ... first(): LDS reads that need what other waves wrote during the previous phase (issued behind the first barrier)
+    auto run_phase = [&](auto y0_, auto y1_, auto r0_, auto r1_, int j0, int j1, auto&& first, auto&& mm, auto&& side) __attribute__((always_inline)) {
+        const int hb = (ph & 1) * HALF, ob = HALF - hb;
+        const char* const sw = smem + hb;
+        u32x4 wa[2][2], wb[2][2];
+        wait_vm<decltype(y0_)::value>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if constexpr (decltype(r0_)::value) {
+            issue(e[0], ob + 3 * SLOT);
+            issue(e[1], ob + 4 * SLOT);
         }
-        // ---- second product: k-tile q of W2 (product columns 64 q .. 64 q + 63 = column tiles 2q | 2q + 1), all row groups
-        u32x4 pf[2][2];  // [k-step = column-tile parity][row tile]: the lane group's eight products, both halves
+        first();
+        rd(sw, wa, j0, j1);
+        rd(sw + SLOT, wb, j0, j1);
+        mm(std::integral_constant<int, 0>{}, wa);
+        side(std::integral_constant<int, 0>{});
+        rd(sw + 2 * SLOT, wa, j0, j1);
+        mm(std::integral_constant<int, 1>{}, wb);
+        side(std::integral_constant<int, 1>{});
+        mm(std::integral_constant<int, 2>{}, wa);
+        side(std::integral_constant<int, 2>{});
+        wait_vm<decltype(y1_)::value>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if constexpr (decltype(r1_)::value) {
+            issue(e[2], hb);
+            issue(e[3], hb + SLOT);
+            issue(e[4], hb + 2 * SLOT);
+        }
+        rd(sw + 3 * SLOT, wa, j0, j1);
+        rd(sw + 4 * SLOT, wb, j0, j1);
+        mm(std::integral_constant<int, 3>{}, wa);
+        side(std::integral_constant<int, 3>{});
+        mm(std::integral_constant<int, 4>{}, wb);
+        side(std::integral_constant<int, 4>{});
+        ++ph;
+        if constexpr (decltype(r1_)::value) {
+            const int nb = KT * ph + KT + 3;
 #pragma unroll
-        for (int g = 0; g < G2; ++g) {
-            const char* sw = slot_begin();
-            if (g == 0) {
+            for (int i = 0; i < KT; ++i) e[i] = order[nb + i];
+        }
+    };
+    auto no_first = []() __attribute__((always_inline)) {};
+    auto steady = [&](int j0, int j1, auto&& first, auto&& mm, auto&& side) __attribute__((always_inline)) {
+        run_phase(std::integral_constant<int, 5>{}, std::integral_constant<int, 5>{}, True{}, True{}, j0, j1, first, mm, side);
+    };
+    const int v0 = h, v1 = 2 + h;          // slots of W1: value tile and gate tile of this wave half
+    const int c0 = 2 * h, c1 = 2 * h + 1;  // slots of W2: the two 16-column tiles of this wave half
+
+    // One quarter of a column tile's GEGLU epilogue: row tile u / 2, columns 2 (u % 2) + {0, 1} of the lane's four.  Lane
+    // holds, for rows mrow0 + 16 i + fr, the values of product columns 32 jt + 8 fq + 4 h + r (acc[0]) and their gates (acc[1]).
+    float o[4];
+    auto gelu_unit = [&](const f32x4 (&acc)[2][2], int jt, int par, int buf, auto u_) __attribute__((always_inline)) {
+        constexpr int u = decltype(u_)::value;
+        constexpr int i = u >> 1, r = (u & 1) * 2;
+        const float* const tb = tab + jt * 128 + fq * 16 + 4 * h + r;
+        const f32x2 bv = *reinterpret_cast<const f32x2*>(tb), bg = *reinterpret_cast<const f32x2*>(tb + 8);
+        const f32x2 cv = *reinterpret_cast<const f32x2*>(tb + 64), cg = *reinterpret_cast<const f32x2*>(tb + 64 + 8);
+        // LN(a) W^T = rstd * (a W'^T - mean * colsum(W')) + (beta W^T + b); two values per packed instruction
+        const f32x2 mu = {ln_mu[i], ln_mu[i]}, rs = {ln_rs[i], ln_rs[i]};
+        const f32x2 gv = rs * (f32x2{acc[1][i][r], acc[1][i][r + 1]} - mu * cg) + bg;
+        const f32x2 vv = rs * (f32x2{acc[0][i][r], acc[0][i][r + 1]} - mu * cv) + bv;
+        const f32x2 pv = vv * gelu_erf_fast_f2(gv);
+        o[r] = pv[0];
+        o[r + 1] = pv[1];
+        if constexpr ((u & 1) != 0)
+            *reinterpret_cast<u32x2*>(pbuf + buf * PBUF + ((((pr * 2 + par) * 2 + i) * 64 + lane) << 4) + 8 * h) =
+                u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+    };
+    auto zero4 = [](f32x4 (&acc)[2][2]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
+        for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        pf[ks][i] = *reinterpret_cast<const u32x4*>(pbuf + ((((pr * 2 + ks) * 2 + i) * 64 + lane) << 4));
-            }
-            u32x4 w[2][2];
-            read_w(sw, 2 * h, 2 * h + 1, w);
+            for (int i = 0; i < 2; ++i) acc[jj][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto nothing = [](auto) __attribute__((always_inline)) {};
+    // the KT slots of one column tile of W1 into `acc`
+    auto phase_w1 = [&](f32x4 (&acc)[2][2], auto&& side) __attribute__((always_inline)) {
+        zero4(acc);
+        steady(v0, v1, no_first, [&](auto k_, const u32x4 (&w)[2][2]) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_)::value;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    Mma16<bf16_t>::mma(acc[0][i], w[ks][0], afr[i][2 * k + ks]);
+                    Mma16<bf16_t>::mma(acc[1][i], w[ks][1], afr[i][2 * k + ks]);
+                }
+        }, side);
+    };
+    // the G2 slots of one k-tile of W2 (product columns of one pair of column tiles): `buf` = exchange buffer of that pair
+    auto phase_w2 = [&](int buf, auto&& side) __attribute__((always_inline)) {
+        // [k-step = column-tile parity][row tile]: the lane group's eight products, both halves.  The partner half wrote its
+        // last piece during the previous phase, behind that phase's second barrier: read behind this phase's first one.
+        u32x4 pf[2][2];
+        auto first = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    pf[ks][i] = *reinterpret_cast<const u32x4*>(pbuf + buf * PBUF + ((((pr * 2 + ks) * 2 + i) * 64 + lane) << 4));
+        };
+        steady(c0, c1, first, [&](auto g_, const u32x4 (&w)[2][2]) __attribute__((always_inline)) {
+            constexpr int g = decltype(g_)::value;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -234,16 +305,35 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(FfnArgs p) {
                     Mma16<bf16_t>::mma(oacc[g][0][i], w[ks][0], pf[ks][i]);
                     Mma16<bf16_t>::mma(oacc[g][1][i], w[ks][1], pf[ks][i]);
                 }
-        }
+        }, side);
+    };
+    f32x4 acc_a[2][2], acc_b[2][2];  // first product of the even / odd column tile of a pair: [value | gate][row tile]
+
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the table writes above; the first barrier publishes them
+    // pair 0 has no earlier pair whose second product could cover the epilogue of its odd tile
+    phase_w1(acc_a, nothing);
+    phase_w1(acc_b, [&](auto k_) __attribute__((always_inline)) {
+        if constexpr (decltype(k_)::value < 4) gelu_unit(acc_a, 0, 0, 0, k_);
+    });
+    static_for<0, 4>([&](auto u_) __attribute__((always_inline)) { gelu_unit(acc_b, 1, 1, 0, u_); });
+    // Pair q: column tile 2q (A), column tile 2q + 1 (B) with the epilogue of A behind its MFMAs, then the k-tile q - 1 of
+    // W2 (C) with the epilogue of B behind its MFMAs; the products of pair q reach the second product one pair later.
+    for (int q = 1; q < NP; ++q) {
+        phase_w1(acc_a, nothing);
+        phase_w1(acc_b, [&](auto k_) __attribute__((always_inline)) {
+            if constexpr (decltype(k_)::value < 4) gelu_unit(acc_a, 2 * q, 0, q & 1, k_);
+        });
+        phase_w2((q - 1) & 1, [&](auto g_) __attribute__((always_inline)) {
+            if constexpr (decltype(g_)::value < 4) gelu_unit(acc_b, 2 * q + 1, 1, q & 1, g_);
+        });
     }
-    // ---- the columns of W2 that multiply t itself (conv_output of the residue)
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int g = 0; g < G2; ++g) {
-            const char* sw = slot_begin();
-            u32x4 w[2][2];
-            read_w(sw, 2 * h, 2 * h + 1, w);
+    phase_w2((NP - 1) & 1, nothing);
+    // ---- the columns of W2 that multiply t itself (conv_output of the residue): KT phases, the last two with the ring draining
+    static_assert(NPH == 3 * NP + KT, "phase count");
+    static_for<0, KT>([&](auto kt_) __attribute__((always_inline)) {
+        constexpr int kt = decltype(kt_)::value;
+        auto mm = [&](auto g_, const u32x4 (&w)[2][2]) __attribute__((always_inline)) {
+            constexpr int g = decltype(g_)::value;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -251,7 +341,13 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(FfnArgs p) {
                     Mma16<bf16_t>::mma(oacc[g][0][i], w[ks][0], afr[i][2 * kt + ks]);
                     Mma16<bf16_t>::mma(oacc[g][1][i], w[ks][1], afr[i][2 * kt + ks]);
                 }
-        }
+        };
+        if constexpr (kt + 2 < KT) steady(c0, c1, no_first, mm, nothing);
+        else if constexpr (kt + 2 == KT)  // last phase but one: nothing left to request behind its second barrier
+            run_phase(std::integral_constant<int, 5>{}, std::integral_constant<int, 5>{}, True{}, False{}, c0, c1, no_first, mm, nothing);
+        else  // last phase: only its own slots 3-4 are younger than slots 0-2
+            run_phase(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, False{}, False{}, c0, c1, no_first, mm, nothing);
+    });
 
     // ---- epilogue: lane holds rows mrow0 + 16 i + fr, columns 64 g + 16 fq + 8 h + 4 jj + r
     __syncthreads();  // every wave is done with the ring: its first bytes become the column-sum exchange buffer
@@ -340,11 +436,11 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(FfnArgs p) {
     }
 }
 
-template <int KT, int STAGES> int launch(const FfnArgs& a, hipStream_t stream) {
+template <int KT> int launch(const FfnArgs& a, hipStream_t stream) {
     static DmLdsAttr attr;
-    auto kfn = ffn_geglu_kernel<KT, STAGES>;
-    constexpr int LDS = STAGES * SLOT + 8 * KT * 128 * 4 + 4 * 2 * 2 * 64 * 16;  // ring + column terms + product exchange
-    static_assert(LDS <= 160 * 1024 && 4 * KT * 64 * 2 * 4 <= STAGES * SLOT, "LDS budget");
+    auto kfn = ffn_geglu_kernel<KT>;
+    constexpr int LDS = 2 * KT * SLOT + 8 * KT * 128 * 4 + 2 * 4 * 2 * 2 * 64 * 16;  // ring + column terms + two product exchange buffers
+    static_assert(LDS <= 160 * 1024 && 4 * KT * 64 * 2 * 4 <= 2 * KT * SLOT, "LDS budget");
     if (const int rc = dm_set_lds_attr(reinterpret_cast<const void*>(kfn), attr, LDS)) return rc;
     hipLaunchKernelGGL(kfn, dim3(a.M / 128), dim3(512), LDS, stream, a);
     return dm_check_launch();
@@ -390,5 +486,5 @@ extern "C" int dm_ffn_geglu(const DmFfnDesc* d, hipStream_t stream) {
     a.stats = dm_group_stats(d->stats, d->ld_stats, d->stats_cpg, d->stats_ch0, d->c_model);
     a.stats2 = dm_group_stats(d->stats2, d->ld_stats2, d->stats2_cpg, d->stats2_ch0, d->c_model);
     a.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : d->m;
-    return launch<5, 8>(a, stream);
+    return launch<5>(a, stream);
 }

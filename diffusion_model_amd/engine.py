@@ -138,6 +138,7 @@ class Engine:
         self.fuse_gn_stats = os.environ.get("DM_FUSE_GN_STATS", "1") == "1"
         # bf16, C = 320: linear_geglu_1 -> GELU gate -> [linear_geglu_2 + residue -> conv_output] as one launch
         self.fuse_ffn = os.environ.get("DM_FUSE_FFN", "1") != "0"
+        self.ffn_min_rows = int(os.environ.get("DM_FFN_MIN_ROWS", str(256 * 128)))
         # fp32: GroupNorm (+ SiLU) applied to the A fragments of the convolution / projection that reads it
         self.fuse_gn_apply = os.environ.get("DM_FUSE_GN_APPLY", "1") != "0"
         # ... for convolutions only up to this many output channels.  The map is redone by every block that reads the
@@ -557,7 +558,9 @@ class Engine:
 
     def ffn_ok(self, m: int, c: int, batch: int) -> bool:
         """Whether the feed-forward half of an AttentionBlock over ``m`` rows of width ``c`` runs as one launch."""
-        return bool(self.fuse_ffn and batch > 0 and m % batch == 0
+        # A block streams both weight images (2.6 MB) for its 128 rows whatever the row count: it pays once every CU has a
+        # block (measured at 64 x 64, bf16: 0.5x the two-launch form at batch 1, 0.8x at 4, 1.1x at 8, 1.4x at 16)
+        return bool(self.fuse_ffn and batch > 0 and m % batch == 0 and m >= self.ffn_min_rows
                     and self.lib.dm_ffn_geglu_supported(self.dm, m, c, m // batch, 1))
 
     def ffn_geglu(self, t: torch.Tensor, pw1: PackedWeight, pw2: PackedWeight, out: torch.Tensor, *,

@@ -829,7 +829,7 @@ def test_ffn_geglu_one_launch(dev, batch, hw, with_x):
         l0.weight.copy_(w0); l0.bias.copy_(b0); l1.weight.copy_(w1); l1.bias.copy_(b1); l2.weight.copy_(w2); l2.bias.copy_(b2)
         ln.weight.copy_(gamma); ln.bias.copy_(beta); co.weight.copy_(wc.reshape(c, c, 1, 1)); co.bias.copy_(bc)
     p0 = eng.pack_linear(l0); p1 = eng.pack_linear(l1, geglu=True, ln=ln); p2 = eng.pack_chain(l2, co)
-    assert eng.ffn_ok(m, c, batch)
+    assert eng.lib.dm_ffn_geglu_supported(eng.dm, m, c, hw, 1)
     t = eng.gemm(up(eng, a0), p0, ln_out=True)  # the residual stream and its row sums
     xd = up(eng, x) if with_x else None
     wide = eng.new(m, c + 64)
@@ -859,7 +859,10 @@ def test_ffn_geglu_refused_where_unsupported(dev):
     """One launch exists for bf16, C = 320 and whole blocks of 128 rows inside one sample; everything else reports so and the
     block runner keeps the two-launch form."""
     eng = _bf16_engine(dev)
-    assert not eng.ffn_ok(4096, 640, 1) and not eng.ffn_ok(4096 + 64, 320, 1) and not eng.ffn_ok(3 * 192, 320, 3)
-    assert not Engine.get(dev, torch.float32).ffn_ok(4096, 320, 1)
+    big = 16 * 4096
+    assert eng.ffn_ok(big, 320, 16)
+    assert not eng.ffn_ok(big, 640, 16) and not eng.ffn_ok(big + 64, 320, 1) and not eng.ffn_ok(342 * 192, 320, 342)
+    assert not eng.ffn_ok(4096, 320, 1)  # too few rows to pay: the block runner keeps two launches
+    assert not Engine.get(dev, torch.float32).ffn_ok(big, 320, 16)
     d = _lib.FfnDesc()
     assert _lib.lib().dm_ffn_geglu(d, None) != 0
