@@ -116,14 +116,15 @@ def cpu_baseline(latent_hw):
 def pmc_traffic(config, batch, latent):
     """HBM bytes per conv3x3 launch from the committed PMC passes of this workload (tools/pmc_traffic.py);
     None when the run is not one of the profiled configurations."""
-    name = {2: "r02_pmc_traffic_config2_f32.json", 3: "r02_pmc_traffic_config3_bf16.json"}.get(config)
+    name = {2: "pmc_traffic_config2_f32.json", 3: "pmc_traffic_config3_bf16.json"}.get(config)
     if name is None or batch != CONFIGS[config]["batch"] or latent != CONFIGS[config]["latent"]:
         return None
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return round(json.load(f)["per_launch"].get("conv3x3", 0.0)) or None
+    for rnd in ("r03_", "r02_"):  # the newest committed pass of the workload
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", rnd + name)
+        if os.path.exists(path):
+            with open(path) as f:
+                return round(json.load(f)["per_launch"].get("conv3x3", 0.0)) or None
+    return None
 
 
 def launch_ranks(n: int) -> int:
@@ -376,8 +377,9 @@ def main():
             "config": {"workload": cfg["name"], "batch_per_gpu": B, "global_batch": global_batch,
                        "latent": f"{HW}x{HW}", "ddpm_steps": T, "hip_graph": sched.use_hip_graph,
                        "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_igemm_kernel" + (" + conv3x3_wide_kernel" if cfg["dtype"] == "bf16"
-                                                                          else " + conv3x3_gn_kernel" if not split else " (conv3x3_split_kernel)"),
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_igemm_kernel + conv3x3_pair_kernel"
+                                                    + (" + conv3x3_wide_kernel" if cfg["dtype"] == "bf16"
+                                                       else " + conv3x3_gn_kernel" if not split else " (conv3x3_split_kernel)"),
                          "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(tflops / peak, 4), "traffic": pmc_traffic(args.config, B, HW),
                          "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, separate passes)",

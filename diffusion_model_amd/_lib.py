@@ -28,6 +28,10 @@ TILE_E128x128, TILE_E128x64, TILE_E64x64, TILE_E64x128 = 24, 25, 26, 27  # early
 TILE_DIMS.update({TILE_E128x128: (128, 128), TILE_E128x64: (128, 64), TILE_E64x64: (64, 64), TILE_E64x128: (64, 128)})
 TILE_DIMS.update({TILE_D256x64_S2: (256, 64), TILE_D128x64_S2: (128, 64), TILE_D64x64_S2: (64, 64),
                   TILE_D256x256_S2: (256, 256)})
+# two k-tiles per barrier (four stages as two halves)
+TILE_U64x64 = 28
+PAIR_TILES = (TILE_U64x64,)
+TILE_DIMS.update({TILE_U64x64: (64, 64)})
 ALL_TILES = tuple(TILE_DIMS)  # tiles every dense / conv problem may use
 # row-panel tiles (bf16, dense, K = 320 / 640): a block owns `bm` rows and all column tiles; DmGemmDesc.splitk counts
 # column slices for them

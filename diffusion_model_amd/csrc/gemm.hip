@@ -28,6 +28,8 @@
 //   GEGLU : value half (j < 2) / gate half (j >= 2) of output column 32*g + 8*q + 4*(j&1) + r
 // so that after the MFMA lane (q = lane>>4) holds columns 64*g + 16*q .. +15 of row m = lane&15
 // (GEGLU: 8 value columns and their 8 gates).
+#include <cstdlib>
+
 #include "common.h"
 #include "dm_hip.h"
 #include "panel.h"
@@ -780,8 +782,12 @@ template <int LOADS, int MAXY> __device__ __forceinline__ void wait_young(int yo
 // direct-to-LDS main loop
 // ------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool CONV, bool EARLY = false, bool GN = false,
-          int SPLIT = 0>
+          int SPLIT = 0, int KU = 1>
 __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
+    // KU = 2: two k-tiles per barrier.  The four LDS stages form two halves of two k-tiles each; a block waits for the pair
+    // it is about to multiply (the only requests outstanding), passes ONE barrier, requests the next pair into the other half
+    // and issues the MFMAs of both tiles: half the waits, barriers and request bursts per MFMA, a whole pair of lead time.
+    static_assert(KU == 1 || (KU == 2 && STAGES == 4 && !EARLY && !GN && SPLIT == 0), "pairs of k-tiles: plain ring loop, four stages");
     // SPLIT: 0 = the operands' own arithmetic, 2 / 3 = fp32 problems with two / three bf16 terms per operand
     static_assert(SPLIT == 0 || ((SPLIT == 2 || SPLIT == 3) && sizeof(T) == 4 && !EARLY && !GN),
                   "split-bf16 weights go with the plain fp32 ring loop");
@@ -1014,7 +1020,25 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
         f32x4 ln_cs[4];
         ln_row_stats<FM>(p, m0 + wm * 16 * FM, n0 + wn * 64, fr, fq, ln_mu, ln_rs, ln_cs);
 
-        if constexpr (EARLY) {
+        if constexpr (KU == 2) {
+            if (kt0 < kt1) issue(kt0, 0);
+            if (kt0 + 1 < kt1) issue(kt0 + 1, 1);
+            int stage = 0;  // first stage of the half that holds the current pair: 0 or 2
+            for (int kt = kt0; kt < kt1; kt += 2) {
+                wait_vm<0>();                  // the current pair has landed: nothing else was requested
+                __builtin_amdgcn_s_barrier();  // ... every wave's share is visible, and all reads of the other half are done
+                const int ns = stage ^ 2;
+                if (kt + 2 < kt1) issue(kt + 2, ns);
+                if (kt + 3 < kt1) issue(kt + 3, ns + 1);
+                const char* sa = smem + stage * STAGE_BYTES;
+                mma_tile<T, FM>(acc, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq);
+                if (kt + 1 < kt1) {
+                    sa += STAGE_BYTES;
+                    mma_tile<T, FM>(acc, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq);
+                }
+                stage = ns;
+            }
+        } else if constexpr (EARLY) {
             // Two LDS buffers, two k-tiles in flight: a tile's fragments are all read into registers first, a
             // second barrier then frees its buffer, and the tile two steps ahead is requested into it before
             // the MFMAs start.  Every request so has almost two iterations to land instead of one.
@@ -1222,6 +1246,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_
 }
 
 // fp32 activations, split-bf16 weight image (mma_tile_split)
+// two k-tiles per barrier (four stages)
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_M* WAVES_N, 4)) void gemm_pair_kernel(GemmArgs p) {
+    gemm_dma_body<T, BM, BN, WAVES_M, WAVES_N, 4, false, false, false, 0, 2>(p);
+}
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_M* WAVES_N, 4)) void conv3x3_pair_kernel(GemmArgs p) {
+    gemm_dma_body<T, BM, BN, WAVES_M, WAVES_N, 4, true, false, false, 0, 2>(p);
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_M* WAVES_N, STAGES)) void gemm_split_kernel(
     GemmArgs p) {
@@ -1774,6 +1808,13 @@ int launch_dma(const GemmArgs& a, hipStream_t s) {
     return launch_kernel(gemm_dma_kernel<T, BM, BN, WM, WN, ST, EARLY>, done, t, a, s);
 }
 
+template <typename T, int BM, int BN, int WM, int WN> int launch_pair(const GemmArgs& a, hipStream_t s) {
+    static DmLdsAttr done, done_conv;
+    const TileInfo t{BM, BN, WM * WN * 64, 4 * (BM + BN) * 128};
+    if (a.conv) return launch_kernel(conv3x3_pair_kernel<T, BM, BN, WM, WN>, done_conv, t, a, s);
+    return launch_kernel(gemm_pair_kernel<T, BM, BN, WM, WN>, done, t, a, s);
+}
+
 // fp32 with the GroupNorm of A applied to the fragments: the scale / shift table sits in LDS behind the ring
 template <int BM, int BN, int WM, int WN, int ST> int launch_gn(const GemmArgs& a, hipStream_t s) {
     static DmLdsAttr done, done_conv;
@@ -1871,6 +1912,7 @@ template <typename T> int launch_typed(const GemmArgs& a, int cfg, hipStream_t s
         case DM_TILE_E128x64: return launch_dma<T, 128, 64, 4, 1, 2, true>(a, s);
         case DM_TILE_E64x64: return launch_dma<T, 64, 64, 4, 1, 2, true>(a, s);
         case DM_TILE_E64x128: return launch_dma<T, 64, 128, 2, 2, 2, true>(a, s);
+        case DM_TILE_U64x64: return launch_pair<T, 64, 64, 4, 1>(a, s);
         default: return DM_ERR_ARG;
     }
 }
@@ -1879,7 +1921,7 @@ template <typename T> int launch_typed(const GemmArgs& a, int cfg, hipStream_t s
 int tile_wave_rows(int cfg) {
     switch (cfg) {
         case DM_TILE_64x64: case DM_TILE_32x64: case DM_TILE_D64x64_S4: case DM_TILE_D64x64_S2: case DM_TILE_D32x64_S4:
-        case DM_TILE_E64x64:
+        case DM_TILE_E64x64: case DM_TILE_U64x64:
             return 16;
         case DM_TILE_64x128: case DM_TILE_D64x128_S3: case DM_TILE_D64x128_S4: case DM_TILE_D128x64_S4:
         case DM_TILE_D128x64_S2: case DM_TILE_E128x64: case DM_TILE_E64x128:
@@ -1895,11 +1937,12 @@ int tile_dims(int cfg, int* bm, int* bn) {
             *bm = 128; *bn = 128; return 0;
         case DM_TILE_64x128: case DM_TILE_D64x128_S3: case DM_TILE_D64x128_S4: case DM_TILE_E64x128:
             *bm = 64; *bn = 128; return 0;
-        case DM_TILE_64x64: case DM_TILE_D64x64_S4: *bm = 64; *bn = 64; return 0;
+        case DM_TILE_64x64: case DM_TILE_D64x64_S4: case DM_TILE_U64x64: *bm = 64; *bn = 64; return 0;
         case DM_TILE_256x128: case DM_TILE_D256x128_S3: *bm = 256; *bn = 128; return 0;
         case DM_TILE_32x64: case DM_TILE_D32x64_S4: *bm = 32; *bn = 64; return 0;
         case DM_TILE_D256x64_S3: *bm = 256; *bn = 64; return 0;
-        case DM_TILE_D128x64_S4: case DM_TILE_D128x64_S2: case DM_TILE_E128x64: *bm = 128; *bn = 64; return 0;
+        case DM_TILE_D128x64_S4: case DM_TILE_D128x64_S2: case DM_TILE_E128x64:
+            *bm = 128; *bn = 64; return 0;
         case DM_TILE_D256x64_S2: *bm = 256; *bn = 64; return 0;
         case DM_TILE_D64x64_S2: case DM_TILE_E64x64: *bm = 64; *bn = 64; return 0;
         case DM_TILE_D256x256_S2: *bm = 256; *bn = 256; return 0;

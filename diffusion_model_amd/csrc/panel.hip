@@ -19,12 +19,11 @@
 //     (bias, GELU, rounding, stores) overlaps the other's MFMA phase without any hand-built schedule;
 //   * a block sees whole output rows: the row sums a following (folded) LayerNorm needs are accumulated in registers
 //     across the column tiles and written once, without atomics.
-// A block is four MFMA waves and one LOADER wave.  vmcnt retires in issue order over loads, stores, atomics and LDS-DMA
-// alike, so a wave that both requests slots and stores results would find its counted slot waits queued behind its own
-// stores (measured: half of every wave's life spent in s_waitcnt).  The loader wave issues nothing but slot requests:
-// its counted s_waitcnt vmcnt(N) is exact, one raw s_barrier per k-tile hands slot t to the MFMA waves and returns
-// slot t-1 to the loader, and STAGES-1 slots stay in flight.  The MFMA waves have no LDS-DMA on their counters at all,
-// so the compiler's own (counted) waits serve their loads and their stores never block an operand.
+// Every wave requests its share of each slot (two LDS-DMA instructions per wave and slot) and counts its own requests with
+// s_waitcnt vmcnt(N): STAGES-1 slots stay in flight, one raw s_barrier per k-tile publishes slot t and retires the reads of slot
+// t-1.  vmcnt retires in issue order over loads, stores, atomics and LDS-DMA alike and the count assumes that only slot requests
+// are younger than the slot waited for, so behind an epilogue (whose stores are younger too) a wait is stricter than needed for a
+// few k-tiles: it also waits for those stores.  That errs on the safe side, never the other way.
 #include "common.h"
 #include "dm_hip.h"
 #include "panel.h"

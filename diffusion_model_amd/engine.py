@@ -626,7 +626,7 @@ class Engine:
     # launch is idempotent: it only rewrites the output) and the winner is cached for the process.
     _TUNE_TILES = (_lib.TILE_D256x256_S2, _lib.TILE_D256x128_S3, _lib.TILE_D128x128_S2, _lib.TILE_D256x64_S2, _lib.TILE_D128x64_S2,
                    _lib.TILE_D64x128_S3, _lib.TILE_D64x64_S4, _lib.TILE_D64x64_S2, _lib.TILE_D32x64_S4,
-                   _lib.TILE_E128x128, _lib.TILE_E128x64)
+                   _lib.TILE_E128x128, _lib.TILE_E128x64) + _lib.PAIR_TILES
     _EARLY_REFILL = (_lib.TILE_E128x128, _lib.TILE_E128x64)  # measured to win only on some bf16 shapes
     _TUNE_SK = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)
     _TUNE_STREAMK = (256, 512, 768, 1024)  # blocks sharing the (tile, k-tile) work list

@@ -516,6 +516,11 @@ def run_vae_attention(eng: Engine, pk: NS, x, batch: int, s: int):
     """Single head of width C (512): wider than the flash kernel's LDS tiles allow, so the scores are materialised
     per sample - Q K^T and P V run on the GEMM kernel with K / V^T packed on the device as its weight operand."""
     c = pk.c
+    if s % eng.epc:
+        # the score matrix [s, s] is a GEMM output and a softmax operand: its rows are accessed as 16-byte pieces
+        raise RuntimeError(f"autoencoder attention over {s} positions: the latent height x width must be a multiple of "
+                           f"{eng.epc} for {'bf16' if eng.esz == 2 else 'fp32'} (image sides that are multiples of "
+                           f"{32 if eng.esz == 2 else 16} always are)")
     out = eng.new(batch * s, c)
     mark = eng.arena.mark()
     qkv = eng.gemm(x, pk.in_proj, gn_in=dict(batch=batch, hw=s, gamma=pk.gn_w, beta=pk.gn_b, eps=pk.gn_eps, silu=False))

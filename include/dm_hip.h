@@ -65,9 +65,12 @@ extern "C" {
 #define DM_TILE_E128x64 25
 #define DM_TILE_E64x64 26
 #define DM_TILE_E64x128 27
+/* U: two k-tiles per barrier.  Four LDS stages as two halves of two k-tiles; the block waits for the pair it is about to
+ * multiply, passes one barrier, requests the next pair into the other half and multiplies both tiles */
+#define DM_TILE_U64x64 28
 /* P: row-panel form for short contractions (bf16, dense, K = 320 or 640, N a multiple of 64, plain or GEGLU
  * epilogue): a block owns 64 / 128 rows, keeps them in registers for the whole launch and walks ALL column
- * tiles of 64 (weights streamed through an LDS ring by a loader wave), so the activations are fetched once and the
+ * tiles of 64 (weights streamed through an LDS ring), so the activations are fetched once and the
  * row sums of a following LayerNorm need no atomics.  For these tiles `splitk` (>= 1) is the number of column slices
  * the column tiles are dealt to (grid.y), not a split of k; no workspace.  P128 exists for K = 320 only. */
 #define DM_TILE_P64 31

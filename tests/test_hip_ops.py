@@ -96,7 +96,7 @@ DMA_TILES = tuple(t for t in _lib.ALL_TILES if t >= _lib.TILE_D128x128_S2)
 
 
 @pytest.mark.parametrize("tile", DMA_TILES)
-@pytest.mark.parametrize("blocks", [1, 7, 64, 300])
+@pytest.mark.parametrize("blocks", [1, 7, 64, 280, 300])  # 280, 300: whole multiples of the tile count (segment-major dealing)
 def test_gemm_streamk(eng, tile, blocks):
     """Work-list form: `blocks` blocks share the (tile, k-tile) list; tiles cut between blocks are summed by
     the last block to arrive.  Two launches in a row: the arrival counters must come back to zero, and the

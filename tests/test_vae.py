@@ -96,6 +96,16 @@ def test_hip_decoder_and_encoder_small(dev, dtype, tol):
     assert mean.shape == lv.shape == (2, 4, 8, 6) and float(lv.max()) <= 20 and float(lv.min()) >= -30
 
 
+@pytest.mark.gpu
+def test_hip_encoder_rejects_a_latent_the_attention_cannot_take(dev):
+    """The mid-block attention runs as GEMMs over an s x s score matrix whose rows are 16-byte pieces: a 24 x 24 image
+    (s = 9) is refused up front with a message that says so, not deep inside a launch."""
+    from diffusion_model_amd.models import Encoder
+    enc = deterministic_fill_(Encoder()).to(dev).eval()
+    with pytest.raises(RuntimeError, match="autoencoder attention over 9 positions"):
+        enc(torch.zeros(1, 3, 24, 24, device=dev), torch.zeros(1, 4, 3, 3, device=dev))
+
+
 @pytest.fixture(scope="module")
 def config5_oracle():
     """CLIP -> 5 DDPM steps at the 96x96 latent -> decode -> uint8, on the CPU oracle (fp32).  Run once per module."""
