@@ -12,15 +12,15 @@ export DM_TUNE_CACHE=/tmp/dm_tune_$CFG.json
 W=/tmp/ev_$CFG; rm -rf $W; mkdir -p $W
 
 # 1. un-profiled run: writes the tuning table the profiled runs read (no tuning launches in their traces)
-timeout -k 10 400 python3 bench.py --config $CFG --no-cpu-baseline > $OUT/${TAG}_nocpu.json 2> $W/b0.err
+timeout -k 10 400 python3 bench.py --config $CFG --no-cpu-baseline --no-secondary > $OUT/${TAG}_nocpu.json 2> $W/b0.err
 echo "[evidence] bench (no cpu leg) done"
 # 2. per-kernel statistics of the bench command
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $W/stats -- python3 bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline > $W/b1.out 2> $W/b1.err
-python3 tools/summarize_rocprof.py $W/stats $TAG "python3 bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $W/stats -- python3 bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $W/b1.out 2> $W/b1.err
+python3 tools/summarize_rocprof.py $W/stats $TAG "python3 bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-secondary"
 cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_kernel_stats.md $OUT/
 echo "[evidence] kernel stats done"
 # 3. one graph-replayed step cut out of a kernel trace
-timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $W/trace -- python3 bench.py --config $CFG --ddpm-steps 4 --steps 1 --warmup 1 --no-cpu-baseline > $W/b2.out 2> $W/b2.err
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $W/trace -- python3 bench.py --config $CFG --ddpm-steps 4 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $W/b2.out 2> $W/b2.err
 python3 tools/trace_forward.py $W/trace --top 60 > $OUT/${TRACE}.txt
 echo "[evidence] step trace done"
 # 4. L2-miss traffic, one counter per pass
@@ -33,7 +33,7 @@ echo "[evidence] pmc traffic done"
 if [ "$CPU" = "cpu" ]; then
   timeout -k 10 600 python3 bench.py --config $CFG > $OUT/${TAG}.json 2> $W/b3.err
 else
-  timeout -k 10 400 python3 bench.py --config $CFG --no-cpu-baseline > $OUT/${TAG}.json 2> $W/b3.err
+  timeout -k 10 400 python3 bench.py --config $CFG --no-cpu-baseline --no-secondary > $OUT/${TAG}.json 2> $W/b3.err
 fi
 echo "[evidence] bench line done"
 tail -c 600 $OUT/${TAG}.json
