@@ -41,21 +41,31 @@ def _compile(src):
     return obj
 
 
-def build_timeline() -> str:
-    """Diagnostic variant libdm_hip_tl.so: the generic GEMM / conv kernel stamps a wall clock at its phase boundaries
-    (tools/timeline_gemm.py loads it through DM_HIP_LIBRARY).  Not shipped, not loaded by the package."""
-    obj_dir = os.path.join(CSRC, "build_tl")
+def build_variant(tag: str, defines) -> str:
+    """A second build of the library with extra preprocessor definitions, libdm_hip_<tag>.so, loaded through
+    DM_HIP_LIBRARY.  Not shipped, not loaded by the package.  `python build.py --timeline` is the diagnostic variant
+    (tag "tl", -DDM_TIMELINE): the generic GEMM / conv kernel stamps a wall clock at its phase boundaries
+    (tools/timeline_gemm.py); `python build.py --variant exp -DNAME ...` builds an experiment."""
+    obj_dir = os.path.join(CSRC, "build_" + tag)
     os.makedirs(obj_dir, exist_ok=True)
+    stamp = os.path.join(obj_dir, "defines.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(defines):
+        for f in os.listdir(obj_dir):
+            os.remove(os.path.join(obj_dir, f))
+        open(stamp, "w").write(" ".join(defines))
     objs = []
     for src in SOURCES:
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
         if _stale(obj, [os.path.join(CSRC, src), *HEADERS]):
-            subprocess.run(["hipcc", *FLAGS, "-DDM_TIMELINE", *EXTRA.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj],
-                           check=True)
+            subprocess.run(["hipcc", *FLAGS, *defines, *EXTRA.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj], check=True)
         objs.append(obj)
-    lib = os.path.join(CSRC, "libdm_hip_tl.so")
+    lib = os.path.join(CSRC, f"libdm_hip_{tag}.so")
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], check=True)
     return lib
+
+
+def build_timeline() -> str:
+    return build_variant("tl", ["-DDM_TIMELINE"])
 
 
 def build(force: bool = False) -> str:
@@ -71,4 +81,8 @@ def build(force: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build_timeline() if "--timeline" in sys.argv else build(force="--force" in sys.argv))
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")]))
+    else:
+        print(build_timeline() if "--timeline" in sys.argv else build(force="--force" in sys.argv))

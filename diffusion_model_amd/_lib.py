@@ -70,6 +70,7 @@ class GemmDesc(C.Structure):
         ("gn_sums", C.c_void_p), ("ld_gn", C.c_long), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
         ("gn_eps", C.c_float), ("gn_silu", C.c_int), ("gn_groups", C.c_int),
         ("w_split", C.c_int),
+        ("conv_chunk_major", C.c_int),
     ]
 
 
@@ -164,7 +165,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dm_abi_version() != 11:
+        if handle.dm_abi_version() != 12:
             raise RuntimeError("libdm_hip.so ABI version mismatch; rebuild with `python build.py`")
         _lib = handle
     return _lib

@@ -74,7 +74,31 @@ struct GemmArgs {
     float gn_eps;
     int gn_groups;
     int gn_c;       // channels that are normalised: Cin (conv) or K - Cin2 (dense)
+    int korder;     // conv: 1 = chunk-major k axis (k-tile = chunk * 9 + tap), see DmGemmDesc.conv_chunk_major
 };
+
+// Chunk-major convolution: (tap, channel offset) of k-tile kt, and the step to the next k-tile.  Tap 9 is the appended
+// pointwise operand, whose channel offset simply runs on.
+__device__ __forceinline__ void chunk_major_at(int kt, int cin, int bk, int& tap, int& c0) {
+    const int nine = 9 * (cin / bk);
+    if (kt < nine) {
+        const int chunk = kt / 9;
+        tap = kt - 9 * chunk;
+        c0 = chunk * bk;
+    } else {
+        tap = 9;
+        c0 = (kt - nine) * bk;
+    }
+}
+__device__ __forceinline__ void chunk_major_next(int cin, int bk, int& tap, int& c0) {
+    if (tap >= 9) {
+        c0 += bk;
+    } else if (++tap == 9) {
+        c0 += bk;
+        if (c0 < cin) tap = 0;
+        else c0 = 0;
+    }
+}
 
 // source of every lane whose 16 bytes must read as zero in the direct-to-LDS loop
 __device__ __attribute__((aligned(16))) uint32_t g_zero16[4];
@@ -97,7 +121,9 @@ __device__ unsigned long long g_timeline[TL_BLOCKS * TL_SLOTS];
             g_timeline[blockIdx.x * TL_SLOTS + (seg) * 8 + 7] = clock64() - tl_cycles;            \
     } while (0)
 // Knock-out switches of the diagnostic build (dm_timeline_variant): bit 1 = no DMA issue inside the k loop, bit 2 = no
-// waits / barrier after the first k-tile, bit 8 = no epilogue at all.  Results are garbage; only durations are of interest.
+// waits / barrier after the first k-tile, bit 8 = no epilogue at all, bit 16 = chunk-major convolution: only tap 0 of a
+// chunk reads the activation (the other taps' requests all read one 16-byte line), bit 32 = every weight request reads
+// that one line.  Results are garbage; only durations are of interest.
 __device__ int g_tl_variant;
 #define DM_TL_ON(bit) (!(tl_variant & (bit)))
 #else
@@ -782,8 +808,9 @@ template <int LOADS, int MAXY> __device__ __forceinline__ void wait_young(int yo
 // direct-to-LDS main loop
 // ------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool CONV, bool EARLY = false, bool GN = false,
-          int SPLIT = 0, int KU = 1>
+          int SPLIT = 0, int KU = 1, bool KORD = false>
 __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
+    static_assert(!KORD || (CONV && sizeof(T) == 2 && !GN && SPLIT == 0), "chunk-major k axis: bf16 convolutions");
     // KU = 2: two k-tiles per barrier.  The four LDS stages form two halves of two k-tiles each; a block waits for the pair
     // it is about to multiply (the only requests outstanding), passes ONE barrier, requests the next pair into the other half
     // and issues the MFMAs of both tiles: half the waits, barriers and request bursts per MFMA, a whole pair of lead time.
@@ -894,6 +921,26 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
         }
         ARows<A_IT> rows;
         init_rows<A_IT, NT / 8>(rows, p, m0, tid >> 3, BM);
+        // Chunk-major convolution (stride 1, same size): the input pixel of (output row m, tap) is row m + dy*Win + dx of
+        // the image matrix, so a request is a wave-uniform base plus this thread's fixed row offset; what differs per row
+        // is whether the tap falls outside the image (bit t of a_mask; bit 9 = the appended pointwise operand).
+        constexpr bool kord = KORD;  // chunk-major k axis (DmGemmDesc.conv_chunk_major): its own kernels, no run-time test
+        [[maybe_unused]] uint32_t a_mask[A_IT];
+        if (CONV) {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                uint32_t bits = 0;
+                if (kord && rows.ok[it]) {
+#pragma unroll
+                    for (int t9 = 0; t9 < 9; ++t9) {
+                        const int iy = rows.y[it] + t9 / 3 - 1, ix = rows.x[it] + t9 % 3 - 1;
+                        if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) bits |= 1u << t9;
+                    }
+                    if (p.A2) bits |= 1u << 9;
+                }
+                a_mask[it] = bits;
+            }
+        }
         // Running source pointers, advanced after every k-tile.  A row (or, in a convolution, a tap of a
         // row) that must read as zero points at the 16-byte zero buffer with step 0, so the steady state
         // costs one 64-bit add per DMA and no select.
@@ -947,8 +994,12 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
         };
         if (fast) {
             if (CONV) {
-                c0 = kc - lchunk * EPC;
-                set_tap();
+                if (kord) {
+                    chunk_major_at(kt0, p.Cin, BK, tap, c0);
+                } else {
+                    c0 = kc - lchunk * EPC;
+                    set_tap();
+                }
             } else {
 #pragma unroll
                 for (int it = 0; it < A_IT; ++it) {
@@ -963,7 +1014,23 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
         auto issue = [&](int kt, int stage) {
             char* sa = smem + stage * STAGE_BYTES + lds_wave;
             char* sw = sa + BM * 128;
-            if (fast) {
+            if (CONV && kord) {
+                const bool second = tap >= 9;
+                const long ld = second ? p.lda2 : p.lda;
+                const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+                const char* base = (second ? p.A2 + ((long)m0 * ld + c0) * sizeof(T)
+                                           : p.A + ((long)(m0 + dy * p.Win + dx) * ld + c0) * sizeof(T)) +
+                                   ((long)(tid >> 3) * ld + lchunk * EPC) * sizeof(T);
+                const long row_step = (long)(NT / 8) * ld * sizeof(T);
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) {
+                    const bool good = ((a_mask[it] >> tap) & 1u) && (DM_TL_ON(16) || tap == 0);
+                    const char* src = good ? base + it * row_step : zsrc;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
+                }
+                chunk_major_next(p.Cin, BK, tap, c0);
+            } else if (fast) {
                 if (!CONV && kt == kt_second) second_operand(kt);  // wave-uniform, once per run
 #pragma unroll
                 for (int it = 0; it < A_IT; ++it) {
@@ -1005,7 +1072,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
             }
 #pragma unroll
             for (int it = 0; it < W_IT; ++it) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[it],
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(DM_TL_ON(32) ? w_ptr[it] : zsrc),
                                                  (__attribute__((address_space(3))) void*)(sw + it * (NT * 16)), 16, 0, 0);
                 w_ptr[it] += WPL * W_KTILE_STEP;
             }
@@ -1112,8 +1179,8 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
             }
             int nstage = stage + STAGES - 1;
             if (nstage >= STAGES) nstage -= STAGES;
-            if (DM_TL_ON(1) && kt + STAGES - 1 < kt1) issue(kt + STAGES - 1, nstage);
             const char* sa = smem + stage * STAGE_BYTES;
+            if (DM_TL_ON(1) && kt + STAGES - 1 < kt1) issue(kt + STAGES - 1, nstage);
             if constexpr (GN) {
                 mma_tile_gn<FM, CONV>(acc, sa, sa + BM * 128, wm * 16 * FM, wn * 64, fr, fq, gn_s4, gn_t4, gn_vmask,
                                       CONV ? gn_tap : 0, gn_raw);
@@ -1244,6 +1311,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_
     GemmArgs p) {
     gemm_dma_body<T, BM, BN, WAVES_M, WAVES_N, STAGES, true, EARLY>(p);
 }
+// bf16, weights with the chunk-major k axis (stride 1, same size)
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool EARLY = false>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_M* WAVES_N, STAGES)) void conv3x3_chunk_kernel(
+    GemmArgs p) {
+    gemm_dma_body<bf16_t, BM, BN, WAVES_M, WAVES_N, STAGES, true, EARLY, false, 0, 1, true>(p);
+}
 
 // fp32 activations, split-bf16 weight image (mma_tile_split)
 // two k-tiles per barrier (four stages)
@@ -1254,6 +1327,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_M* WAVES_N, 4)) void conv3x3_pair_kernel(GemmArgs p) {
     gemm_dma_body<T, BM, BN, WAVES_M, WAVES_N, 4, true, false, false, 0, 2>(p);
+}
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_M* WAVES_N, 4)) void conv3x3_chunk_pair_kernel(GemmArgs p) {
+    gemm_dma_body<bf16_t, BM, BN, WAVES_M, WAVES_N, 4, true, false, false, 0, 2, true>(p);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
@@ -1434,7 +1511,11 @@ __device__ __forceinline__ void gemm_wide_body(const GemmArgs& p) {
             }
         }
         int tap[2], c0[2];  // conv: tap and channel offset of the next k-tile to request, per A half
-        if (CONV) {
+        if (CONV && p.korder) {
+            chunk_major_at(kt0, p.Cin, BK, tap[0], c0[0]);
+            tap[1] = tap[0];
+            c0[1] = c0[0];
+        } else if (CONV) {
             const int kc = kt0 * BK;
             tap[0] = tap[1] = min(kc / p.Cin, 9);
             c0[0] = c0[1] = kc - tap[0] * p.Cin;
@@ -1474,7 +1555,9 @@ __device__ __forceinline__ void gemm_wide_body(const GemmArgs& p) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(dst + it * 8192), 16, 0, 0);
             }
-            if (CONV) {
+            if (CONV && p.korder) {
+                chunk_major_next(p.Cin, BK, tap[h], c0[h]);
+            } else if (CONV) {
                 c0[h] += BK;
                 if (c0[h] == p.Cin && tap[h] < 9) {
                     c0[h] = 0;
@@ -1804,6 +1887,11 @@ template <typename T, int BM, int BN, int WM, int WN, int ST, bool EARLY = false
 int launch_dma(const GemmArgs& a, hipStream_t s) {
     static DmLdsAttr done, done_conv;
     const TileInfo t{BM, BN, WM * WN * 64, ST * (BM + BN) * 128};
+    if constexpr (sizeof(T) == 2) {
+        static DmLdsAttr done_chunk;
+        if (a.conv && a.korder) return launch_kernel(conv3x3_chunk_kernel<BM, BN, WM, WN, ST, EARLY>, done_chunk, t, a, s);
+    }
+    if (a.korder) return DM_ERR_ARG;
     if (a.conv) return launch_kernel(conv3x3_igemm_kernel<T, BM, BN, WM, WN, ST, EARLY>, done_conv, t, a, s);
     return launch_kernel(gemm_dma_kernel<T, BM, BN, WM, WN, ST, EARLY>, done, t, a, s);
 }
@@ -1811,6 +1899,11 @@ int launch_dma(const GemmArgs& a, hipStream_t s) {
 template <typename T, int BM, int BN, int WM, int WN> int launch_pair(const GemmArgs& a, hipStream_t s) {
     static DmLdsAttr done, done_conv;
     const TileInfo t{BM, BN, WM * WN * 64, 4 * (BM + BN) * 128};
+    if constexpr (sizeof(T) == 2) {
+        static DmLdsAttr done_chunk;
+        if (a.conv && a.korder) return launch_kernel(conv3x3_chunk_pair_kernel<BM, BN, WM, WN>, done_chunk, t, a, s);
+    }
+    if (a.korder) return DM_ERR_ARG;
     if (a.conv) return launch_kernel(conv3x3_pair_kernel<T, BM, BN, WM, WN>, done_conv, t, a, s);
     return launch_kernel(gemm_pair_kernel<T, BM, BN, WM, WN>, done, t, a, s);
 }
@@ -2173,6 +2266,12 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     int bm, bn;
     if (tile_dims(tile, &bm, &bn)) return DM_ERR_ARG;
     if (d->a2 && tile < DM_TILE_D128x128_S2) return DM_ERR_ARG;  // only the direct-to-LDS loop reads a second operand
+    if (d->conv_chunk_major) {
+        // chunk-major k axis: bf16, direct-to-LDS loops only, row-linear addressing (stride 1, same size, padding 1)
+        if (!d->conv || d->dtype != DM_BF16 || d->gn_sums || tile < DM_TILE_D128x128_S2 || d->w_split || d->cin % bk ||
+            d->stride != 1 || d->up || d->pad_hi_only || d->hin != d->hout || d->win != d->wout)
+            return DM_ERR_ARG;
+    }
     if (tile == DM_TILE_D256x256_S2) {
         // bf16, whole k-tiles only (conv: channels a multiple of the k-tile; dense: no padded k tail), no legacy split-K
         // convolutions: stride 1, same size (input pixel = output row + tap offset)
@@ -2258,6 +2357,7 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     a.gn_eps = d->gn_eps;
     a.gn_groups = d->gn_groups;
     a.gn_c = gn_c;
+    a.korder = d->conv_chunk_major ? 1 : 0;
 
     int rc = d->gn_sums ? launch_gn_typed(a, tile, stream)
              : d->w_split ? launch_split_typed(a, tile, d->w_split, stream)

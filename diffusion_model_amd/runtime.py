@@ -57,11 +57,11 @@ def pack_residual_block(m, eng: Engine) -> NS:
     return NS(kind="res", cin=cin, cout=cout,
               gn1_w=_f32(eng, m.groupnorm_feature.weight), gn1_b=_f32(eng, m.groupnorm_feature.bias),
               gn1_eps=m.groupnorm_feature.eps,
-              conv1=eng.pack_conv3x3(m.conv_feature),
+              conv1=eng.pack_conv3x3(m.conv_feature, same_size=True),
               lt_w=_f32(eng, m.linear_time.weight), lt_b=_f32(eng, m.linear_time.bias),
               gn2_w=_f32(eng, m.groupnorm_merged.weight), gn2_b=_f32(eng, m.groupnorm_merged.bias),
               gn2_eps=m.groupnorm_merged.eps,
-              conv2=eng.pack_conv3x3(m.conv_merged, skip=m.residual_layer if fold else None),
+              conv2=eng.pack_conv3x3(m.conv_merged, skip=m.residual_layer if fold else None, same_size=True),
               res=None if (fold or isinstance(m.residual_layer, torch.nn.Identity)) else eng.pack_conv1x1(m.residual_layer),
               fold_skip=fold, t_off=0)
 
@@ -98,12 +98,12 @@ def pack_attention_block(m, eng: Engine) -> NS:
 
 def pack_conv_layer(conv: torch.nn.Conv2d, eng: Engine, up: bool = False) -> NS:
     return NS(kind="up" if up else "conv", cin=conv.in_channels, cout=conv.out_channels, stride=conv.stride[0],
-              w=eng.pack_conv3x3(conv))
+              w=eng.pack_conv3x3(conv, same_size=not up and conv.stride[0] == 1))
 
 
 def pack_final_layer(m, eng: Engine) -> NS:
     return NS(gn_w=_f32(eng, m.group_norm.weight), gn_b=_f32(eng, m.group_norm.bias), gn_eps=m.group_norm.eps,
-              cin=m.conv.in_channels, cout=m.conv.out_channels, conv=eng.pack_conv3x3(m.conv))
+              cin=m.conv.in_channels, cout=m.conv.out_channels, conv=eng.pack_conv3x3(m.conv, same_size=True))
 
 
 def pack_time_embedding(m, eng: Engine) -> NS:
@@ -420,9 +420,9 @@ def pack_vae_residual(m, eng: Engine) -> NS:
     fold = (eng.fuse_skip and isinstance(m.residual_layer, torch.nn.Conv2d) and cin % eng.bk == 0 and cout % eng.bk == 0)
     return NS(kind="vres", cin=cin, cout=cout,
               gn1_w=_f32(eng, m.groupnorm_feature.weight), gn1_b=_f32(eng, m.groupnorm_feature.bias), gn1_eps=m.groupnorm_feature.eps,
-              conv1=eng.pack_conv3x3(m.conv_feature),
+              conv1=eng.pack_conv3x3(m.conv_feature, same_size=True),
               gn2_w=_f32(eng, m.groupnorm_merged.weight), gn2_b=_f32(eng, m.groupnorm_merged.bias), gn2_eps=m.groupnorm_merged.eps,
-              conv2=eng.pack_conv3x3(m.conv_merged, skip=m.residual_layer if fold else None),
+              conv2=eng.pack_conv3x3(m.conv_merged, skip=m.residual_layer if fold else None, same_size=True),
               res=None if (fold or isinstance(m.residual_layer, torch.nn.Identity)) else eng.pack_conv1x1(m.residual_layer),
               fold_skip=fold)
 
@@ -481,7 +481,7 @@ def pack_vae_layers(layers, eng: Engine) -> List[NS]:
                 if not asym and m.padding != (1, 1):
                     raise RuntimeError("VAE convolutions are 3x3 with padding 1, or stride 2 with the (0,1,0,1) padding")
                 ops.append(NS(kind="conv", cin=cin, cout=cout, cols=npd, stride=m.stride[0], pad_hi_only=int(asym),
-                              w=eng.pack_conv3x3(conv)))
+                              w=eng.pack_conv3x3(conv, same_size=m.stride == (1, 1))))
             else:
                 raise RuntimeError("unsupported convolution in the autoencoder")
         elif isinstance(m, torch.nn.GroupNorm):

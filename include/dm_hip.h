@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 11
+#define DM_ABI_VERSION 12
 
 #define DM_F32 0
 #define DM_BF16 1
@@ -183,6 +183,15 @@ typedef struct DmGemmDesc {
      *    dropped is 2^-24 of a product.  The image has two 128-byte rows per packed row and k-tile, stored
      *    [npad/64][kpad/32][2 planes][64 rows][128 B]: plane 0 = 32 hi | 32 mid terms, plane 1 = 32 lo terms | zeros. */
     int w_split;
+    /* conv3x3 only.  0: the packed k axis runs tap-major (k = tap * cin + c: all channels of tap 0, then tap 1, ...).
+     * 1: chunk-major - the channels are cut into k-tiles (64 bf16 values) and the nine taps of one chunk
+     *    follow each other (k-tile index = chunk * 9 + tap), any pointwise operand still last.  The nine requests for a
+     *    chunk then touch the same few image rows back to back and all but the first are served by the XCD's L2; in
+     *    tap-major order a tap returns to a pixel only after cin / k-tile steps, long after the line has left L2.
+     *    bf16 only (the exact-fp32 loop moves an eighth of the operand bytes per MFMA cycle and only pays the extra
+     *    address arithmetic).  Needs stride 1, equal input and output size, no fused upsampling, padding 1, cin a whole
+     *    number of k-tiles and a direct-to-LDS tile (not DM_TILE_128x128 .. DM_TILE_32x64). */
+    int conv_chunk_major;
 } DmGemmDesc;
 
 int dm_gemm(const DmGemmDesc* d, hipStream_t stream);

@@ -151,6 +151,72 @@ def test_gemm_streamk_geglu_and_conv(eng, blocks):
     assert int(eng.ws_sk[:4096].max()) == 0
 
 
+@pytest.mark.parametrize("tile,sk", [(_lib.TILE_D128x128_S2, 1), (_lib.TILE_D128x128_S2, -50), (_lib.TILE_D256x128_S3, -100),
+                                     (_lib.TILE_D64x128_S3, -37), (_lib.TILE_D64x64_S4, 1), (_lib.TILE_D32x64_S4, -9),
+                                     (_lib.TILE_D256x64_S2, 1), (_lib.TILE_E128x128, -11), (_lib.TILE_E128x64, 1),
+                                     (_lib.TILE_U64x64, 1), (_lib.TILE_U64x64, -29),
+                                     (_lib.TILE_D256x256_S2, 1), (_lib.TILE_D256x256_S2, -23)])
+@pytest.mark.parametrize("pointwise", [False, True])
+def test_conv3x3_chunk_major_k_order(eng, tile, sk, pointwise):
+    """Weights packed for stride-1 same-size use (k axis ordered channel chunk, then tap; DmGemmDesc.conv_chunk_major)
+    against torch's convolution (blocks.py:60,70 are such convolutions) and against the tap-major image of the same
+    weights; odd image sizes and three samples, so tiles cross image rows and samples and every border tap is masked
+    somewhere.  Any other geometry is refused for such weights."""
+    if eng.dtype != torch.bfloat16:
+        conv = torch.nn.Conv2d(64, 64, 3, padding=1)
+        assert not eng.pack_conv3x3(conv, same_size=True).chunk_major  # the fp32 engine keeps the tap-major image
+        pytest.skip("chunk-major k axis: bf16 only")
+    bsz, h, wd, cin, cout, c2 = 3, 9, 7, 192, 320, 64
+    m = bsz * h * wd
+    x = tin("cm.x", (bsz, cin, h, wd)); wt = tin("cm.w", (cout, cin, 3, 3), scale=1 / math.sqrt(9 * cin)); bias = tin("cm.b", (cout,))
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(wt); conv.bias.copy_(bias)
+    ref = F.conv2d(rnd(x, eng.dtype), rnd(wt, eng.dtype), bias, padding=1)
+    skip, extra = None, {}
+    if pointwise:
+        skip = torch.nn.Conv2d(c2, cout, 1)
+        ws = tin("cm.sw", (cout, c2, 1, 1), scale=1 / math.sqrt(c2)); bs = tin("cm.sb", (cout,)); s_in = tin("cm.s", (m, c2))
+        with torch.no_grad():
+            skip.weight.copy_(ws); skip.bias.copy_(bs)
+        ref = ref + F.conv2d(rnd(s_in, eng.dtype).reshape(bsz, h, wd, c2).permute(0, 3, 1, 2), rnd(ws, eng.dtype), bs)
+        extra = dict(skip=up(eng, s_in))
+    rows = eng.nchw_to_rows(x.to(eng.device), cpad=cin)
+    geom = dict(batch=bsz, hin=h, win=wd, hout=h, wout=wd, cin_real=cin, **extra)
+    pw = eng.pack_conv3x3(conv, skip=skip, same_size=True)
+    pw_tap = eng.pack_conv3x3(conv, skip=skip)
+    assert pw.chunk_major and not pw_tap.chunk_major
+    assert not torch.equal(pw.w, pw_tap.w)
+    eng.tile_override = (tile, sk)
+    try:
+        out = eng.gemm(rows, pw, conv=geom)
+        out_tap = eng.gemm(rows, pw_tap, conv=geom)
+        with pytest.raises(RuntimeError):
+            eng.gemm(rows, pw, conv=dict(geom, hout=(h + 1) // 2, wout=(wd + 1) // 2, stride=2))
+    finally:
+        eng.tile_override = None
+    assert max_rel(eng.rows_to_nchw(out, bsz, cout, h, wd), ref) < tol(eng.dtype)
+    # the same products summed in another order
+    assert max_rel(out.float(), out_tap.float()) < (2e-6 if eng.dtype == torch.float32 else 1e-2)
+    assert int(eng.ws_sk[:4096].max()) == 0
+
+
+def test_conv3x3_chunk_major_needs_whole_k_tiles(eng):
+    """Channel counts that are not whole k-tiles keep the tap-major image whatever the caller promises; the library
+    refuses the chunk-major flag for fp32 problems."""
+    if eng.dtype == torch.float32:
+        conv = torch.nn.Conv2d(64, 64, 3, padding=1)
+        pw = eng.pack_conv3x3(conv, same_size=True)
+        pw.chunk_major = True  # force the flag into the descriptor
+        x = torch.zeros(2 * 8 * 8, 64, device=eng.device)
+        with pytest.raises(RuntimeError):
+            eng.gemm(x, pw, conv=dict(batch=2, hin=8, win=8, hout=8, wout=8, cin_real=64))
+    conv = torch.nn.Conv2d(4, 320, 3, padding=1)
+    assert not eng.pack_conv3x3(conv, same_size=True).chunk_major
+    conv = torch.nn.Conv2d(48, 64, 3, padding=1)
+    assert not eng.pack_conv3x3(conv, same_size=True).chunk_major
+
+
 @pytest.mark.parametrize("tile,sk", [(_lib.TILE_D128x128_S2, 1), (_lib.TILE_D256x128_S3, -100), (_lib.TILE_D64x64_S2, -37),
                                      (_lib.TILE_D128x64_S2, 1), (_lib.TILE_64x64, 1), (_lib.TILE_D32x64_S4, -9),
                                      (_lib.TILE_D256x256_S2, 1), (_lib.TILE_D256x256_S2, -23)])
@@ -247,9 +313,13 @@ def test_gemm_groupnorm_on_a_fragments(dev, tile, sk, kind):
                     skip.weight.copy_(ws); skip.bias.copy_(bs)
                 s_in = tin("gnf.s", (m, c2))
                 ref = ref + F.conv2d(s_in.reshape(b, h, w, c2).permute(0, 3, 1, 2), ws, bs)
-                out = eng.gemm(x, eng.pack_conv3x3(conv, skip=skip), conv=dict(geom, skip=up(eng, s_in)), gn_in=gn)
+                # same_size: what the model passes for these convolutions; the fp32 engine keeps the tap-major image
+                pw = eng.pack_conv3x3(conv, skip=skip, same_size=True)
+                out = eng.gemm(x, pw, conv=dict(geom, skip=up(eng, s_in)), gn_in=gn)
             else:
-                out = eng.gemm(x, eng.pack_conv3x3(conv), conv=geom, gn_in=gn)
+                pw = eng.pack_conv3x3(conv, same_size=True)
+                out = eng.gemm(x, pw, conv=geom, gn_in=gn)
+            assert not pw.chunk_major
             ref = ref.permute(0, 2, 3, 1).reshape(m, n)
     finally:
         eng.tile_override = None

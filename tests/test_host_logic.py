@@ -235,9 +235,10 @@ def test_shipped_tile_table_is_well_formed():
         for key, (tile, split) in rows.items():
             k = ast.literal_eval(key)
             # 13 fields, plus (fp32) the marker of the launches that normalise their A operand themselves or of the
-            # opt-in split-bf16 product modes
-            assert isinstance(k, tuple) and (len(k) == 13 or (len(k) == 14 and k[13] in ("gn_in", "w_split", "w_split3")
-                                                              and "float32" in dtype))
+            # opt-in split-bf16 product modes, or (bf16) of stride-1 convolution weights with the chunk-major k axis
+            assert isinstance(k, tuple) and (len(k) == 13 or (len(k) == 14 and (
+                (k[13] in ("gn_in", "w_split", "w_split3") and "float32" in dtype)
+                or (k[13] == "chunk_major" and "bfloat16" in dtype and k[3] == 1 and k[4] == 1 and k[5] == 0))))
             assert k[0] > 0 and k[1] > 0 and k[2] > 0
             assert tile in _lib.TILE_DIMS
             assert split != 0

@@ -25,6 +25,8 @@ ap.add_argument("--custom", default="", help="extra dense shapes m,n,k;m,n,k;...
 ap.add_argument("--nobias", action="store_true", help="launch without the bias vector (epilogue without its column loads)")
 ap.add_argument("--plain", action="store_true", help="pack the wide layers without the GEGLU epilogue")
 ap.add_argument("--ldc0", action="store_true", help="every output row lands on row 0 (store issue cost without the DRAM traffic)")
+ap.add_argument("--same-size", action="store_true", help="pack the convolution weights chunk-major (stride-1 same-size form)")
+ap.add_argument("--conv", default="", help="convolution shapes cin,cout,hw;... (run instead of the built-in lists)")
 ap.add_argument("--apad", type=int, default=0, help="extra elements in the row stride of A (channel-interleave experiments)")
 args = ap.parse_args()
 
@@ -61,7 +63,7 @@ def run(kind, cin, cout, hw, m_custom=0):
     gen = torch.Generator(device=dev).manual_seed(0)
     if kind == "conv":
         conv = torch.nn.Conv2d(cin, cout, 3, padding=1).to(dev)
-        pw = eng.pack_conv3x3(conv)
+        pw = eng.pack_conv3x3(conv, same_size=args.same_size)
         m = B * hw * hw
         a = (torch.randn(m, cin + args.apad, device=dev, generator=gen)).to(dt)[:, :cin]
         geom = dict(batch=B, hin=hw, win=hw, hout=hw, wout=hw, cin_real=cin)
@@ -99,6 +101,10 @@ def run(kind, cin, cout, hw, m_custom=0):
     print(label.ljust(38), " | ".join(res), flush=True)
 
 
+if args.conv:
+    for spec in args.conv.split(";"):
+        run("conv", *(int(v) for v in spec.split(",")))
+    sys.exit(0)
 if args.custom:
     for spec in args.custom.split(";"):
         m_, n_, k_ = (int(v) for v in spec.split(","))

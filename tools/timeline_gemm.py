@@ -28,7 +28,7 @@ eng = Engine.get(dev, dt)
 eng.tile_override = (tile, sk)
 if sys.argv[4] == "conv":
     b, cin, cout, hw = (int(v) for v in sys.argv[5:9])
-    pw = eng.pack_conv3x3(torch.nn.Conv2d(cin, cout, 3, padding=1).to(dev))
+    pw = eng.pack_conv3x3(torch.nn.Conv2d(cin, cout, 3, padding=1).to(dev), same_size=os.environ.get("DM_TL_TAP_MAJOR", "0") != "1")
     a = torch.randn(b * hw * hw, cin, device=dev).to(dt)
     geom = dict(batch=b, hin=hw, win=hw, hout=hw, wout=hw, cin_real=cin)
 else:
