@@ -1870,10 +1870,19 @@ struct TileInfo {
 // lds_attr: the dynamic-LDS ceiling registered for the kernel when launches of it differ in their LDS size
 template <typename K> int launch_kernel(K kfn, DmLdsAttr& attr_done, const TileInfo& t, const GemmArgs& a, hipStream_t stream,
                                         int lds_attr = 0) {
-    if (const int rc = dm_set_lds_attr(reinterpret_cast<const void*>(kfn), attr_done, lds_attr ? lds_attr : t.lds)) return rc;
+    int lds = t.lds;
+#ifdef DM_TIMELINE
+    // diagnostic build: DM_TL_LDS_PAD=<bytes> of unused LDS per block (fewer co-resident blocks per CU, same code)
+    static const int pad = getenv("DM_TL_LDS_PAD") ? atoi(getenv("DM_TL_LDS_PAD")) : 0;
+    if (pad > 0 && lds + pad <= 160 * 1024) {
+        lds += pad;
+        if (!lds_attr || lds_attr < lds) lds_attr = lds;
+    }
+#endif
+    if (const int rc = dm_set_lds_attr(reinterpret_cast<const void*>(kfn), attr_done, lds_attr ? lds_attr : lds)) return rc;
     const int ntm = (a.M + t.bm - 1) / t.bm, ntn = (a.N + t.bn - 1) / t.bn;
     dim3 grid(a.streamk ? a.streamk : ntm * ntn, a.splitk > 1 ? a.splitk : 1, 1);
-    hipLaunchKernelGGL(kfn, grid, dim3(t.threads), t.lds, stream, a);
+    hipLaunchKernelGGL(kfn, grid, dim3(t.threads), lds, stream, a);
     return dm_check_launch();
 }
 
