@@ -184,19 +184,24 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(FfnArgs p) {
     int e[KT];
 #pragma unroll
     for (int i = 0; i < KT; ++i) e[i] = order[KT + 3 + i];
-    auto rd = [&](const char* sw, u32x4 (&dst)[2][2], int j0, int j1) __attribute__((always_inline)) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            dst[ks][0] = *reinterpret_cast<const u32x4*>(sw + swz(j0 * 16 + fr, ks * 4 + fq));
-            dst[ks][1] = *reinterpret_cast<const u32x4*>(sw + swz(j1 * 16 + fr, ks * 4 + fq));
-        }
+    // Fragment addresses.  swz(16 j + fr, 4 ks + fq) = 2048 j + frag0 for k-step 0 and the same with bit 6 flipped for k-step 1
+    // (the swizzle term (row >> 1) & 7 does not depend on j): one register per lane, two adds per phase, everything else an
+    // immediate offset of the read.
+    const int frag0 = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
+    auto rd = [&](const char* s0, const char* s1, u32x4 (&dst)[2][2], auto dj_, int off) __attribute__((always_inline)) {
+        constexpr int dj = decltype(dj_)::value * 2048;
+        dst[0][0] = *reinterpret_cast<const u32x4*>(s0 + off);
+        dst[0][1] = *reinterpret_cast<const u32x4*>(s0 + off + dj);
+        dst[1][0] = *reinterpret_cast<const u32x4*>(s1 + off);
+        dst[1][1] = *reinterpret_cast<const u32x4*>(s1 + off + dj);
     };
-    // j0, j1: the wave's two 16-row tiles in every slot of the phase; mm(k_, fragments): the MFMAs of slot k; side(k_): VALU
-    // work placed behind them
+    // j0, j0 + dj: the wave's two 16-row tiles in every slot of the phase; mm(k_, fragments): the MFMAs of slot k; side(k_):
+    // VALU work placed behind them
     // ... first(): LDS reads that need what other waves wrote during the previous phase (issued behind the first barrier)
-    auto run_phase = [&](auto y0_, auto y1_, auto r0_, auto r1_, int j0, int j1, auto&& first, auto&& mm, auto&& side) __attribute__((always_inline)) {
+    auto run_phase = [&](auto y0_, auto y1_, auto r0_, auto r1_, int j0, auto dj_, auto&& first, auto&& mm, auto&& side) __attribute__((always_inline)) {
         const int hb = (ph & 1) * HALF, ob = HALF - hb;
-        const char* const sw = smem + hb;
+        const char* const s0 = smem + hb + j0 * 2048 + frag0;
+        const char* const s1 = smem + hb + j0 * 2048 + (frag0 ^ 64);
         u32x4 wa[2][2], wb[2][2];
         wait_vm<decltype(y0_)::value>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -206,11 +211,11 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(FfnArgs p) {
             issue(e[1], ob + 4 * SLOT);
         }
         first();
-        rd(sw, wa, j0, j1);
-        rd(sw + SLOT, wb, j0, j1);
+        rd(s0, s1, wa, dj_, 0);
+        rd(s0, s1, wb, dj_, SLOT);
         mm(std::integral_constant<int, 0>{}, wa);
         side(std::integral_constant<int, 0>{});
-        rd(sw + 2 * SLOT, wa, j0, j1);
+        rd(s0, s1, wa, dj_, 2 * SLOT);
         mm(std::integral_constant<int, 1>{}, wb);
         side(std::integral_constant<int, 1>{});
         mm(std::integral_constant<int, 2>{}, wa);
@@ -223,8 +228,8 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(FfnArgs p) {
             issue(e[3], hb + SLOT);
             issue(e[4], hb + 2 * SLOT);
         }
-        rd(sw + 3 * SLOT, wa, j0, j1);
-        rd(sw + 4 * SLOT, wb, j0, j1);
+        rd(s0, s1, wa, dj_, 3 * SLOT);
+        rd(s0, s1, wb, dj_, 4 * SLOT);
         mm(std::integral_constant<int, 3>{}, wa);
         side(std::integral_constant<int, 3>{});
         mm(std::integral_constant<int, 4>{}, wb);
@@ -237,11 +242,13 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(FfnArgs p) {
         }
     };
     auto no_first = []() __attribute__((always_inline)) {};
-    auto steady = [&](int j0, int j1, auto&& first, auto&& mm, auto&& side) __attribute__((always_inline)) {
-        run_phase(std::integral_constant<int, 5>{}, std::integral_constant<int, 5>{}, True{}, True{}, j0, j1, first, mm, side);
+    auto steady = [&](int j0, auto dj_, auto&& first, auto&& mm, auto&& side) __attribute__((always_inline)) {
+        run_phase(std::integral_constant<int, 5>{}, std::integral_constant<int, 5>{}, True{}, True{}, j0, dj_, first, mm, side);
     };
-    const int v0 = h, v1 = 2 + h;          // slots of W1: value tile and gate tile of this wave half
-    const int c0 = 2 * h, c1 = 2 * h + 1;  // slots of W2: the two 16-column tiles of this wave half
+    const int v0 = h;      // slots of W1: value tile h and gate tile 2 + h of this wave half
+    const int c0 = 2 * h;  // slots of W2: the two 16-column tiles 2 h, 2 h + 1 of this wave half
+    constexpr std::integral_constant<int, 2> DJ_W1{};
+    constexpr std::integral_constant<int, 1> DJ_W2{};
 
     // One quarter of a column tile's GEGLU epilogue: row tile u / 2, columns 2 (u % 2) + {0, 1} of the lane's four.  Lane
     // holds, for rows mrow0 + 16 i + fr, the values of product columns 32 jt + 8 fq + 4 h + r (acc[0]) and their gates (acc[1]).
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(FfnArgs p) {
     // the KT slots of one column tile of W1 into `acc`
     auto phase_w1 = [&](f32x4 (&acc)[2][2], auto&& side) __attribute__((always_inline)) {
         zero4(acc);
-        steady(v0, v1, no_first, [&](auto k_, const u32x4 (&w)[2][2]) __attribute__((always_inline)) {
+        steady(v0, DJ_W1, no_first, [&](auto k_, const u32x4 (&w)[2][2]) __attribute__((always_inline)) {
             constexpr int k = decltype(k_)::value;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(FfnArgs p) {
                 for (int i = 0; i < 2; ++i)
                     pf[ks][i] = *reinterpret_cast<const u32x4*>(pbuf + buf * PBUF + ((((pr * 2 + ks) * 2 + i) * 64 + lane) << 4));
         };
-        steady(c0, c1, first, [&](auto g_, const u32x4 (&w)[2][2]) __attribute__((always_inline)) {
+        steady(c0, DJ_W2, first, [&](auto g_, const u32x4 (&w)[2][2]) __attribute__((always_inline)) {
             constexpr int g = decltype(g_)::value;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -342,11 +349,11 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(FfnArgs p) {
                     Mma16<bf16_t>::mma(oacc[g][1][i], w[ks][1], afr[i][2 * kt + ks]);
                 }
         };
-        if constexpr (kt + 2 < KT) steady(c0, c1, no_first, mm, nothing);
+        if constexpr (kt + 2 < KT) steady(c0, DJ_W2, no_first, mm, nothing);
         else if constexpr (kt + 2 == KT)  // last phase but one: nothing left to request behind its second barrier
-            run_phase(std::integral_constant<int, 5>{}, std::integral_constant<int, 5>{}, True{}, False{}, c0, c1, no_first, mm, nothing);
+            run_phase(std::integral_constant<int, 5>{}, std::integral_constant<int, 5>{}, True{}, False{}, c0, DJ_W2, no_first, mm, nothing);
         else  // last phase: only its own slots 3-4 are younger than slots 0-2
-            run_phase(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, False{}, False{}, c0, c1, no_first, mm, nothing);
+            run_phase(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, False{}, False{}, c0, DJ_W2, no_first, mm, nothing);
     });
 
     // ---- epilogue: lane holds rows mrow0 + 16 i + fr, columns 64 g + 16 fq + 8 h + 4 jj + r
