@@ -565,8 +565,13 @@ template <typename T, int D> int attn_launch(const AttnArgs& a, int batch, hipSt
     // key tile for 14 MFMAs, and with four or five such waves per SIMD the LDS pipe, not the MFMA or exp rate, sets
     // the pace; 32 rows per wave halve those bytes per row and win once there are enough blocks to keep every CU
     // supplied (S = 4096, d = 40 at batch 16: 623 -> 480 us; S = 256, d = 160: 24.0 -> 20.1 us), and lose below
-    // that (batch 1, S = 4096: 61.8 -> 65.2 us).  64 rows per wave never beat 32.
+    // that (batch 1, S = 4096: 61.8 -> 65.2 us).  64 rows per wave win only for d = 40 with a long key loop and at least
+    // 4096 64-row tiles (S = 4096 at batch 8 / 16 / 32: 296 -> 280, 463 -> 442 inside the U-Net, 1046 -> 1003 us; batch 4: a
+    // tie; batch 2, d = 80 and the 77-key cross-attention: 6-15 % slower).
     if constexpr (sizeof(T) == 2) {
+        if constexpr (D == 40) {
+            if (forced == 0 && per64 >= 4096 && a.sk >= 1024) return attn_launch_qt<T, D, 4>(a, batch, s);
+        }
         if (forced == 0 && (per64 >= 1024 || (per64 >= 512 && D >= 160))) return attn_launch_qt<T, D, 2>(a, batch, s);
     }
     // Far fewer 64-row blocks than CUs and a long MFMA chain per key tile (fp32, wide heads): split the head

@@ -608,6 +608,20 @@ def test_attention(eng, d, sq, sk):
     assert max_rel(out.float().reshape(b, sq, c), ref) < (2e-5 if eng.dtype == torch.float32 else 2e-2)
 
 
+def test_attention_many_query_tiles_long_key_loop(eng):
+    """d = 40 with at least 4096 64-row query tiles and 1024+ keys: the shape class for which the bf16 launcher takes 64
+    query rows per wave (blocks.py:26-31 at the 64 x 64 level from batch 8 up).  Ragged query and key tails, a late spike
+    that forces the online-softmax rescale."""
+    b, heads, d, sq, sk = 2, 8, 40, 16390, 1030
+    c = heads * d
+    q = tin("atl.q", (b, sq, c)); k = tin("atl.k", (b, sk, c)); v = tin("atl.v", (b, sk, c))
+    k[:, sk - 3] *= 6.0
+    qr, kr, vr = (up(eng, t.reshape(-1, c)) for t in (q, k, v))
+    out = eng.attention(qr, kr, vr, b, heads, sq, sk, d)
+    ref = ref_attention(rnd(q, eng.dtype), rnd(k, eng.dtype), rnd(v, eng.dtype), heads)
+    assert max_rel(out.float().reshape(b, sq, c), ref) < (2e-5 if eng.dtype == torch.float32 else 2e-2)
+
+
 # ------------------------------------------------------------------------------------------- time path
 @pytest.mark.parametrize("d,sq,sk", [(40, 256, 256), (40, 64, 77), (80, 100, 100), (80, 256, 77), (160, 320, 300), (64, 130, 45)])
 @pytest.mark.parametrize("causal", [False, True])
