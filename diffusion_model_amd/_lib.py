@@ -33,6 +33,9 @@ TILE_U64x64 = 28
 PAIR_TILES = (TILE_U64x64,)
 TILE_DIMS.update({TILE_U64x64: (64, 64)})
 ALL_TILES = tuple(TILE_DIMS)  # tiles every dense / conv problem may use
+# bf16 stride-1 3x3 convolutions with the chunk's activation (and its border) resident in LDS; own weight order
+TILE_H128x128 = 29
+TILE_DIMS.update({TILE_H128x128: (128, 128)})
 # row-panel tiles (bf16, dense, K = 320 / 640): a block owns `bm` rows and all column tiles; DmGemmDesc.splitk counts
 # column slices for them
 TILE_P64, TILE_P128 = 31, 32
@@ -97,6 +100,7 @@ _PROTOS = {
     "dm_gemm_plan": (None, [_i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "dm_gemm_workspace_bytes": (C.c_long, [_i, _i, _i]),
     "dm_gemm_streamk_workspace_bytes": (C.c_long, [_i, _i, _i, _i]),
+    "dm_conv_halo_supported": (C.c_int, [_i, _i, _i, _i, C.c_long]),
     "dm_gemm_stats_supported": (C.c_int, [_i, _i, _i]),
     "dm_gemm_panel_supported": (C.c_int, [C.POINTER(GemmDesc), _i, _i]),
     "dm_gemm_gn_supported": (C.c_int, [_i, _i, _i, _i, _i, _i, _i]),
@@ -165,7 +169,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dm_abi_version() != 12:
+        if handle.dm_abi_version() != 13:
             raise RuntimeError("libdm_hip.so ABI version mismatch; rebuild with `python build.py`")
         _lib = handle
     return _lib

@@ -808,9 +808,16 @@ template <int LOADS, int MAXY> __device__ __forceinline__ void wait_young(int yo
 // direct-to-LDS main loop
 // ------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool CONV, bool EARLY = false, bool GN = false,
-          int SPLIT = 0, int KU = 1, bool KORD = false>
+          int SPLIT = 0, int KU = 1, bool KORD = false, bool HALO = false>
 __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
     static_assert(!KORD || (CONV && sizeof(T) == 2 && !GN && SPLIT == 0), "chunk-major k axis: bf16 convolutions");
+    // HALO: the activation of a 64-channel chunk sits in LDS once, as the tile's pixels plus a one-pixel border (two
+    // half-chunks of 32 channels, 96-byte pixel pitch: 16 consecutive pixels are then read by ds_read_b128 at full rate
+    // from any starting pixel, which 64-, 80- and 128-byte pitches are not), and the nine taps read it at nine offsets; only the weights are
+    // requested per k-tile.  k axis of the weights: per chunk the 18 (half, tap) units in the order half-major, two units
+    // per k-tile, so that half 0 is dead after k-tile 4 of a chunk and is refilled with the next chunk's while half 1 is read.
+    static_assert(!HALO || (KORD && BM == 128 && BN == 128 && WAVES_M == 2 && WAVES_N == 2 && STAGES == 2 && KU == 1 && !EARLY),
+                  "activation halo in LDS: 128 x 128 tile, four waves, two weight stages");
     // KU = 2: two k-tiles per barrier.  The four LDS stages form two halves of two k-tiles each; a block waits for the pair
     // it is about to multiply (the only requests outstanding), passes ONE barrier, requests the next pair into the other half
     // and issues the MFMAs of both tiles: half the waits, barriers and request bursts per MFMA, a whole pair of lead time.
@@ -952,6 +959,37 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
             const int plane = WPL > 1 ? vr / BN : 0, wrow = n0 + vr - plane * BN;
             w_ptr[it] = p.W + ((((long)(wrow >> 6) * nkt + kt0) * WPL + plane) * 64 + (wrow & 63)) * 128 + lchunk * 16;
         }
+        // ---- HALO: where this thread's pieces of a half-chunk image come from, and where its fragment rows sit in it
+        constexpr int HALO_BYTES = 20480;   // 204 pixel slots of 96 bytes and the tail of the last wave's request
+        constexpr int HALO_BASE = 2 * 16384;  // behind the two weight stages
+        [[maybe_unused]] uint32_t hoff[6];  // byte offset from p.A of the piece's 16 bytes at channel 0; ~0 = reads as zero
+        [[maybe_unused]] uint32_t lc[FM];   // byte offset of fragment row i of this lane inside a half-chunk image (centre tap)
+        [[maybe_unused]] int h_pitch = 0, h_pieces = 0;
+        if constexpr (HALO) {
+            const int Wd = p.Win, HW = p.Hin * Wd;
+            const int R = min(BM / Wd, p.Hin), RW = R * Wd;  // image rows and pixels of one group of the tile
+            h_pitch = Wd + 2;
+            const int SG = (R + 2) * h_pitch;                // slots of one group
+            h_pieces = (BM / RW) * SG * 6;                   // 16-byte pieces of a half-chunk image (a slot's last two are padding)
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int piece = it * NT + tid;
+                const int slot = piece / 6, ch = piece - slot * 6;
+                const int g = slot / SG, rs = slot - g * SG;
+                const int ry = rs / h_pitch, rx = rs - ry * h_pitch;
+                const int p0 = m0 + g * RW, b = p0 / HW;
+                const int y = (p0 - b * HW) / Wd + ry - 1, x = rx - 1;
+                const bool ok = piece < h_pieces && ch < 4 && (unsigned)x < (unsigned)Wd && (unsigned)y < (unsigned)p.Hin;
+                hoff[it] = ok ? (uint32_t)((((long)b * HW + (long)y * Wd + x) * p.lda + ch * 8) * 2) : 0xffffffffu;
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int px = wm * 16 * FM + i * 16 + fr;
+                const int g = px / RW, q = px - g * RW;
+                const int y = q / Wd, x = q - y * Wd;
+                lc[i] = (uint32_t)((g * SG + (y + 1) * h_pitch + x + 1) * 96 + fq * 16);
+            }
+        }
         int kc = kt0 * BK + lchunk * EPC, tap = 0;
         if (CONV) {
             tap = min(kc / p.Cin, 9);  // tap 9: the appended pointwise operand (only with A2)
@@ -1087,7 +1125,87 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& p) {
         f32x4 ln_cs[4];
         ln_row_stats<FM>(p, m0 + wm * 16 * FM, n0 + wn * 64, fr, fq, ln_mu, ln_rs, ln_cs);
 
-        if constexpr (KU == 2) {
+        if constexpr (HALO) {
+            const int nchunk = p.Cin / BK, nine = 9 * nchunk;
+            // one half-chunk image: at most six requests per thread, whole waves past the image's end request nothing
+            auto issue_halo = [&](int h, int c) {
+                const char* base = p.A + ((long)c * BK + h * 32) * sizeof(T);
+                char* dst = smem + HALO_BASE + h * HALO_BYTES + lds_wave;
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    if (it * NT + wave * 64 >= h_pieces) continue;  // wave-uniform
+                    const char* src = hoff[it] != 0xffffffffu ? base + hoff[it] : zsrc;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(dst + it * (NT * 16)), 16, 0, 0);
+                }
+            };
+            // the weights of k-tile kt into weight stage ws; behind the chunks, the k-tile of the pointwise operand as a plain
+            // 128-row A tile into the (then idle) image area of the same parity
+            auto issue_w = [&](int kt, int ws) {
+                if (kt >= nine) {
+                    const char* base = p.A2 + ((long)m0 * p.lda2 + (long)(kt - nine) * BK) * sizeof(T) +
+                                       ((long)(tid >> 3) * p.lda2 + lchunk * EPC) * sizeof(T);
+                    const long row_step = (long)(NT / 8) * p.lda2 * sizeof(T);
+                    char* sa = smem + HALO_BASE + ((kt - nine) & 1) * HALO_BYTES + lds_wave;
+#pragma unroll
+                    for (int it = 0; it < A_IT; ++it) {
+                        const char* src = ((a_mask[it] >> 9) & 1u) ? base + it * row_step : zsrc;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                         (__attribute__((address_space(3))) void*)(sa + it * (NT * 16)), 16, 0, 0);
+                    }
+                }
+                char* sw = smem + ws * 16384 + lds_wave;
+#pragma unroll
+                for (int it = 0; it < W_IT; ++it) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[it],
+                                                     (__attribute__((address_space(3))) void*)(sw + it * (NT * 16)), 16, 0, 0);
+                    w_ptr[it] += W_KTILE_STEP;
+                }
+            };
+            int c = 0, j = 0;  // chunk and k-tile inside it of the k-tile about to be consumed
+            if (kt0 < nine) {
+                c = kt0 / 9;
+                j = kt0 - 9 * c;
+                if (j <= 4) issue_halo(0, c);
+                else if (j > 5 && c + 1 < nchunk) issue_halo(0, c + 1);
+                issue_halo(1, c);
+            }
+            if (kt0 < kt1) issue_w(kt0, 0);
+            int stage = 0;
+            for (int kt = kt0; kt < kt1; ++kt) {
+                wait_vm<0>();
+                __builtin_amdgcn_s_barrier();
+                if (kt + 1 < kt1) issue_w(kt + 1, stage ^ 1);
+                const char* sw = smem + stage * 16384;
+                if (kt < nine) {
+                    // half 1 was last read by k-tile 8 of the previous chunk, half 0 by k-tile 4 of this one
+                    if (j == 0 && kt != kt0) issue_halo(1, c);
+                    if (j == 5 && c + 1 < nchunk && (c + 1) * 9 < kt1) issue_halo(0, c + 1);
+                    u32x4 af[2][FM], wf[2][4];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int u = 2 * j + ks, h = u >= 9 ? 1 : 0, t = u - 9 * h;
+                        const int dy = t / 3, dx = t - 3 * dy;
+                        const char* hb = smem + HALO_BASE + h * HALO_BYTES + ((dy - 1) * h_pitch + dx - 1) * 96;
+#pragma unroll
+                        for (int jn = 0; jn < 4; ++jn)
+                            wf[ks][jn] = *reinterpret_cast<const u32x4*>(sw + swz(wn * 64 + jn * 16 + fr, ks * 4 + fq));
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) af[ks][i] = *reinterpret_cast<const u32x4*>(hb + lc[i]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_tile_frags<T, FM>(acc, af, wf);
+                    if (++j == 9) {
+                        j = 0;
+                        ++c;
+                    }
+                } else {
+                    const char* sa = smem + HALO_BASE + ((kt - nine) & 1) * HALO_BYTES;
+                    mma_tile<T, FM>(acc, sa, sw, wm * 16 * FM, wn * 64, fr, fq);
+                }
+                stage ^= 1;
+            }
+        } else if constexpr (KU == 2) {
             if (kt0 < kt1) issue(kt0, 0);
             if (kt0 + 1 < kt1) issue(kt0 + 1, 1);
             int stage = 0;  // first stage of the half that holds the current pair: 0 or 2
@@ -1327,6 +1445,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_M* WAVES_N, 4)) void conv3x3_pair_kernel(GemmArgs p) {
     gemm_dma_body<T, BM, BN, WAVES_M, WAVES_N, 4, true, false, false, 0, 2>(p);
+}
+// bf16, the chunk's activation resident in LDS with its border (weights in the half-major unit order)
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs p) {
+    gemm_dma_body<bf16_t, 128, 128, 2, 2, 2, true, false, false, 0, 1, true, true>(p);
 }
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, dma_min_waves(BM, BN, WAVES_M* WAVES_N, 4)) void conv3x3_chunk_pair_kernel(GemmArgs p) {
@@ -1898,7 +2020,7 @@ int launch_dma(const GemmArgs& a, hipStream_t s) {
     const TileInfo t{BM, BN, WM * WN * 64, ST * (BM + BN) * 128};
     if constexpr (sizeof(T) == 2) {
         static DmLdsAttr done_chunk;
-        if (a.conv && a.korder) return launch_kernel(conv3x3_chunk_kernel<BM, BN, WM, WN, ST, EARLY>, done_chunk, t, a, s);
+        if (a.conv && a.korder == 1) return launch_kernel(conv3x3_chunk_kernel<BM, BN, WM, WN, ST, EARLY>, done_chunk, t, a, s);
     }
     if (a.korder) return DM_ERR_ARG;
     if (a.conv) return launch_kernel(conv3x3_igemm_kernel<T, BM, BN, WM, WN, ST, EARLY>, done_conv, t, a, s);
@@ -1910,11 +2032,21 @@ template <typename T, int BM, int BN, int WM, int WN> int launch_pair(const Gemm
     const TileInfo t{BM, BN, WM * WN * 64, 4 * (BM + BN) * 128};
     if constexpr (sizeof(T) == 2) {
         static DmLdsAttr done_chunk;
-        if (a.conv && a.korder) return launch_kernel(conv3x3_chunk_pair_kernel<BM, BN, WM, WN>, done_chunk, t, a, s);
+        if (a.conv && a.korder == 1) return launch_kernel(conv3x3_chunk_pair_kernel<BM, BN, WM, WN>, done_chunk, t, a, s);
     }
     if (a.korder) return DM_ERR_ARG;
     if (a.conv) return launch_kernel(conv3x3_pair_kernel<T, BM, BN, WM, WN>, done_conv, t, a, s);
     return launch_kernel(gemm_pair_kernel<T, BM, BN, WM, WN>, done, t, a, s);
+}
+
+template <typename T> int launch_halo(const GemmArgs& a, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        static DmLdsAttr done;
+        const TileInfo t{128, 128, 256, 2 * 16384 + 2 * 20480};
+        if (!a.conv || a.korder != 2 || a.splitk > 1) return DM_ERR_ARG;
+        return launch_kernel(conv3x3_halo_kernel, done, t, a, s);
+    }
+    return DM_ERR_ARG;
 }
 
 // fp32 with the GroupNorm of A applied to the fragments: the scale / shift table sits in LDS behind the ring
@@ -2015,6 +2147,7 @@ template <typename T> int launch_typed(const GemmArgs& a, int cfg, hipStream_t s
         case DM_TILE_E64x64: return launch_dma<T, 64, 64, 4, 1, 2, true>(a, s);
         case DM_TILE_E64x128: return launch_dma<T, 64, 128, 2, 2, 2, true>(a, s);
         case DM_TILE_U64x64: return launch_pair<T, 64, 64, 4, 1>(a, s);
+        case DM_TILE_H128x128: return launch_halo<T>(a, s);
         default: return DM_ERR_ARG;
     }
 }
@@ -2036,6 +2169,7 @@ int tile_wave_rows(int cfg) {
 int tile_dims(int cfg, int* bm, int* bn) {
     switch (cfg) {
         case DM_TILE_128x128: case DM_TILE_D128x128_S2: case DM_TILE_D128x128_S3: case DM_TILE_E128x128:
+        case DM_TILE_H128x128:
             *bm = 128; *bn = 128; return 0;
         case DM_TILE_64x128: case DM_TILE_D64x128_S3: case DM_TILE_D64x128_S4: case DM_TILE_E64x128:
             *bm = 64; *bn = 128; return 0;
@@ -2218,6 +2352,18 @@ extern "C" long dm_gemm_streamk_workspace_bytes(int tile, int M, int N, int bloc
     return counters + 2L * blocks * bm * bn * (long)sizeof(float);
 }
 
+// Geometry the halo tile takes: a 128-row tile is G groups of R whole image rows inside one image (R = min(128 / W, H)),
+// every group plus its one-pixel border fits the LDS image (204 slots: images up to 32 pixels wide), 32-bit source offsets
+// reach the whole tensor.
+extern "C" int dm_conv_halo_supported(int m, int h, int w, int cin, long lda) {
+    if (m <= 0 || h <= 0 || w <= 0 || w > 32 || 128 % w || m % 128 || cin <= 0 || cin % 64) return 0;
+    const int r = 128 / w < h ? 128 / w : h;
+    const int rw = r * w;
+    if (h % r || 128 % rw || m % (h * w)) return 0;
+    if ((128 / rw) * (r + 2) * (w + 2) > 204) return 0;
+    return (long)m * lda * 2 < (1L << 32);
+}
+
 extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     if (!d || !d->a || !d->w || !d->c) return DM_ERR_ARG;
     if (d->m <= 0 || d->n <= 0 || d->k <= 0) return DM_ERR_ARG;
@@ -2280,6 +2426,11 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
         if (!d->conv || d->dtype != DM_BF16 || d->gn_sums || tile < DM_TILE_D128x128_S2 || d->w_split || d->cin % bk ||
             d->stride != 1 || d->up || d->pad_hi_only || d->hin != d->hout || d->win != d->wout)
             return DM_ERR_ARG;
+        if (d->conv_chunk_major != 1 && d->conv_chunk_major != 2) return DM_ERR_ARG;
+        if ((d->conv_chunk_major == 2) != (tile == DM_TILE_H128x128)) return DM_ERR_ARG;  // the halo tile and its weight order go together
+        if (tile == DM_TILE_H128x128 && !dm_conv_halo_supported(d->m, d->hin, d->win, d->cin, d->lda)) return DM_ERR_ARG;
+    } else if (tile == DM_TILE_H128x128) {
+        return DM_ERR_ARG;
     }
     if (tile == DM_TILE_D256x256_S2) {
         // bf16, whole k-tiles only (conv: channels a multiple of the k-tile; dense: no padded k tail), no legacy split-K
@@ -2366,7 +2517,7 @@ extern "C" int dm_gemm(const DmGemmDesc* d, hipStream_t stream) {
     a.gn_eps = d->gn_eps;
     a.gn_groups = d->gn_groups;
     a.gn_c = gn_c;
-    a.korder = d->conv_chunk_major ? 1 : 0;
+    a.korder = d->conv_chunk_major;
 
     int rc = d->gn_sums ? launch_gn_typed(a, tile, stream)
              : d->w_split ? launch_split_typed(a, tile, d->w_split, stream)

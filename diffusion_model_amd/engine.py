@@ -72,7 +72,7 @@ class Arena:
 class PackedWeight:
     """Weight matrix in the GEMM kernel's layout plus its fp32 bias."""
     __slots__ = ("w", "n", "k", "npad", "kpad", "bias", "geglu", "conv_cin", "colsum", "ln_eps", "skip_cin", "split",
-                 "chunk_major")
+                 "chunk_major", "w_halo")
 
     def __init__(self, w, n, k, npad, kpad, bias, geglu=False, conv_cin=0):
         self.w, self.n, self.k, self.npad, self.kpad = w, n, k, npad, kpad
@@ -82,6 +82,7 @@ class PackedWeight:
         self.skip_cin = 0  # conv3x3 packed with a pointwise term over a second tensor: its channel count
         self.split = 0  # fp32 weights stored as 2 or 3 bf16 terms per value (Engine.split_bf16); 0 = plain image
         self.chunk_major = False  # conv3x3: k axis ordered (channel chunk, tap) instead of (tap, channel)
+        self.w_halo = None  # conv3x3, chunk-major: second image in the unit order of the halo tile (_lib.TILE_H128x128)
 
 
 class Engine:
@@ -146,6 +147,8 @@ class Engine:
         # then hit) and is worth 1 % of their time.  The exact-fp32 loop moves an eighth of the operand bytes per MFMA
         # cycle and would only pay the per-request address arithmetic (measured 5 % slower at batch 1): bf16 only.
         self.conv_chunk_major = os.environ.get("DM_CONV_CHUNK_MAJOR", "1") != "0" and dtype == torch.bfloat16
+        # ... and a second image of those weights for the tile that keeps the activation of a chunk resident in LDS
+        self.conv_halo = os.environ.get("DM_CONV_HALO", "1") != "0" and self.conv_chunk_major
         # fp32: GroupNorm (+ SiLU) applied to the A fragments of the convolution / projection that reads it
         self.fuse_gn_apply = os.environ.get("DM_FUSE_GN_APPLY", "1") != "0"
         # ... for convolutions only up to this many output channels.  The map is redone by every block that reads the
@@ -388,9 +391,19 @@ class Engine:
             # (Cout, tap, chunk, bk) -> (Cout, chunk, tap, bk): k-tile index = chunk * 9 + tap
             w = w.reshape(conv.out_channels, 9, cpad // self.bk, self.bk).permute(0, 2, 1, 3)
         w2d = w.reshape(conv.out_channels, 9 * cpad)
+        # the halo tile reads the same weights in its own k order: per chunk (half of 32 channels, tap, 32 values)
+        w2d_halo = None
+        if chunk_major and self.conv_halo:
+            wt = conv.weight.detach().permute(0, 2, 3, 1)
+            if cpad != cin:
+                wt = torch.nn.functional.pad(wt, (0, cpad - cin))
+            w2d_halo = wt.reshape(conv.out_channels, 9, cpad // self.bk, 2, self.bk // 2).permute(0, 2, 3, 1, 4) \
+                         .reshape(conv.out_channels, 9 * cpad)
         if skip is None:
             pw = self.pack_matrix(w2d, conv.bias, conv_cin=cpad)
             pw.chunk_major = chunk_major
+            if w2d_halo is not None:
+                pw.w_halo = self.pack_matrix(w2d_halo, None, conv_cin=cpad).w
             return pw
         cin2 = skip.in_channels
         if cpad % self.bk or cin2 % self.bk or skip.out_channels != conv.out_channels:
@@ -402,6 +415,9 @@ class Engine:
         pw = self.pack_matrix(w2d, bias, conv_cin=cpad)
         pw.skip_cin = cin2
         pw.chunk_major = chunk_major
+        if w2d_halo is not None:
+            w2d_halo = torch.cat([w2d_halo, skip.weight.detach().reshape(skip.out_channels, cin2)], dim=1)
+            pw.w_halo = self.pack_matrix(w2d_halo, None, conv_cin=cpad).w
         return pw
 
     # ------------------------------------------------------------------ operators
@@ -511,6 +527,7 @@ class Engine:
                 self._bind_gn(d, gn_rec, gn_in)
             best = self.tuned.get(key)
             if best is None and self.autotune and not self.arena.frozen and self.profile is None:
+                self._tune_pw = pw
                 best = self._tune(d, key, legacy=not no_legacy)
             if best is not None:
                 tile.value, sk.value = best
@@ -520,6 +537,7 @@ class Engine:
         if (ln_in is not None or ln_out) and sk.value > 1 and not panel:
             sk.value = 1  # the separate split-K reduction launch does not carry the LayerNorm epilogue
         d.tile, d.splitk = tile.value, sk.value
+        self._bind_conv_image(d, pw)
         if gn_rec is not None:
             if self.tile_override is not None:
                 self._bind_gn(d, gn_rec, gn_in)
@@ -651,7 +669,7 @@ class Engine:
     # launch is idempotent: it only rewrites the output) and the winner is cached for the process.
     _TUNE_TILES = (_lib.TILE_D256x256_S2, _lib.TILE_D256x128_S3, _lib.TILE_D128x128_S2, _lib.TILE_D256x64_S2, _lib.TILE_D128x64_S2,
                    _lib.TILE_D64x128_S3, _lib.TILE_D64x64_S4, _lib.TILE_D64x64_S2, _lib.TILE_D32x64_S4,
-                   _lib.TILE_E128x128, _lib.TILE_E128x64) + _lib.PAIR_TILES
+                   _lib.TILE_E128x128, _lib.TILE_E128x64, _lib.TILE_H128x128) + _lib.PAIR_TILES
     _EARLY_REFILL = (_lib.TILE_E128x128, _lib.TILE_E128x64)  # measured to win only on some bf16 shapes
     _TUNE_SK = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)
     _TUNE_STREAMK = (256, 512, 768, 1024)  # blocks sharing the (tile, k-tile) work list
@@ -693,8 +711,19 @@ class Engine:
         """Row sums accumulated by the GEMM that wrote ``t`` (``ln_out=True``)."""
         return self._ln_stats[t.data_ptr()]
 
+    def _bind_conv_image(self, d: GemmDesc, pw: PackedWeight):
+        """The halo tile reads its own image of a convolution's weights; every other tile the ordinary one."""
+        if d.tile == _lib.TILE_H128x128:
+            if pw.w_halo is None:
+                raise RuntimeError("the halo tile needs convolution weights packed with same_size=True on a bf16 engine")
+            d.w, d.conv_chunk_major = pw.w_halo.data_ptr(), 2
+        elif d.conv:
+            d.w, d.conv_chunk_major = pw.w.data_ptr(), int(pw.chunk_major)
+
     def _bind_choice(self, d: GemmDesc, tile: int, sk: int):
         d.tile, d.splitk = tile, sk
+        if d.conv and getattr(self, "_tune_pw", None) is not None:
+            self._bind_conv_image(d, self._tune_pw)
         if tile in _lib.PANEL_TILES:
             return
         if sk > 1:
@@ -712,6 +741,11 @@ class Engine:
                 continue
             if tile == _lib.TILE_D256x256_S2 and self.dtype != torch.bfloat16:
                 continue
+            if tile == _lib.TILE_H128x128:
+                pw_t = getattr(self, "_tune_pw", None)
+                if (pw_t is None or pw_t.w_halo is None or not d.conv
+                        or not self.lib.dm_conv_halo_supported(d.m, d.hin, d.win, d.cin, d.lda)):
+                    continue
             if tile in self._EARLY_REFILL and (self.dtype != torch.bfloat16 or not self.tune_early):
                 continue
             blocks = ((d.m + bm - 1) // bm) * ((d.n + bn - 1) // bn)
@@ -722,6 +756,8 @@ class Engine:
                                or d.m * d.n * sk * 4 > (256 << 20)):
                     break
                 d.tile, d.splitk = tile, sk
+                if d.conv:
+                    self._bind_conv_image(d, self._tune_pw)
                 if sk > 1:
                     self._bind_workspace(d, d.m, d.n, sk)
                 t = self._time_candidate(d)
@@ -738,6 +774,8 @@ class Engine:
                 if grid >= 2 * blocks * nkt:
                     break
                 d.tile, d.splitk = tile, -grid
+                if d.conv:
+                    self._bind_conv_image(d, self._tune_pw)
                 if self.lib.dm_gemm_streamk_workspace_bytes(tile, d.m, d.n, grid) < 0:
                     break
                 self._bind_streamk(d, tile, d.m, d.n, grid)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 12
+#define DM_ABI_VERSION 13
 
 #define DM_F32 0
 #define DM_BF16 1
@@ -68,6 +68,11 @@ extern "C" {
 /* U: two k-tiles per barrier.  Four LDS stages as two halves of two k-tiles; the block waits for the pair it is about to
  * multiply, passes one barrier, requests the next pair into the other half and multiplies both tiles */
 #define DM_TILE_U64x64 28
+/* H: 128 x 128, bf16 stride-1 same-size 3x3 convolutions on images at most 32 pixels wide.  The activation of a 64-channel
+ * chunk is held in LDS once - the tile's pixels and a one-pixel border, as two half-chunks of 32 channels - and the nine taps
+ * read it at nine offsets, so a k-tile requests weights only (a third fewer requests than the ring loop, where every tap
+ * fetches its own shifted copy).  Goes with conv_chunk_major = 2 (dm_conv_halo_supported says which geometries qualify). */
+#define DM_TILE_H128x128 29
 /* P: row-panel form for short contractions (bf16, dense, K = 320 or 640, N a multiple of 64, plain or GEGLU
  * epilogue): a block owns 64 / 128 rows, keeps them in registers for the whole launch and walks ALL column
  * tiles of 64 (weights streamed through an LDS ring), so the activations are fetched once and the
@@ -191,10 +196,15 @@ typedef struct DmGemmDesc {
      *    bf16 only (the exact-fp32 loop moves an eighth of the operand bytes per MFMA cycle and only pays the extra
      *    address arithmetic).  Needs stride 1, equal input and output size, no fused upsampling, padding 1, cin a whole
      *    number of k-tiles and a direct-to-LDS tile (not DM_TILE_128x128 .. DM_TILE_32x64). */
+    /* 2: the order of DM_TILE_H128x128 (and only of it): per 64-channel chunk the 18 units (half h of 32 channels, tap t)
+     *    in the order h-major, t-minor, 32 values each, i.e. k = chunk * 576 + (h * 9 + t) * 32 + e; pointwise operand last. */
     int conv_chunk_major;
 } DmGemmDesc;
 
 int dm_gemm(const DmGemmDesc* d, hipStream_t stream);
+/* Whether DM_TILE_H128x128 takes a stride-1 same-size 3x3 convolution over m = batch * h * w output pixels of h x w images
+ * with cin channels and row stride lda (elements).  No counterpart in the reference: a property of this library's tile. */
+int dm_conv_halo_supported(int m, int h, int w, int cin, long lda);
 void dm_gemm_plan(int dtype, int m, int n, int k, int epi, int* tile, int* splitk);
 long dm_gemm_workspace_bytes(int m, int n, int splitk);
 /* -1: the tile has no work-list form, or the problem has more output tiles (2M) than the counter area holds.  The

@@ -201,6 +201,52 @@ def test_conv3x3_chunk_major_k_order(eng, tile, sk, pointwise):
     assert int(eng.ws_sk[:4096].max()) == 0
 
 
+@pytest.mark.parametrize("geom", [(4, 8, 8), (2, 16, 16), (1, 32, 32), (1, 64, 64), (3, 16, 8)])
+@pytest.mark.parametrize("sk", [1, -7, -50])
+@pytest.mark.parametrize("pointwise", [False, True])
+def test_conv3x3_halo_tile(eng, geom, sk, pointwise):
+    """The tile that keeps a chunk's activation and its one-pixel border in LDS (DM_TILE_H128x128, weights in its own unit
+    order) against torch's convolution (blocks.py:60,70): every image width it takes, tiles of several whole images, of
+    several rows and of part of an image, work lists that cut a chunk anywhere, the pointwise operand behind the chunks."""
+    if eng.dtype != torch.bfloat16:
+        pytest.skip("halo tile: bf16 only")
+    bsz, h, wd = geom
+    cin, cout, c2 = 192, 320, 64
+    m = bsz * h * wd
+    x = tin("hl.x", (bsz, cin, h, wd)); wt = tin("hl.w", (cout, cin, 3, 3), scale=1 / math.sqrt(9 * cin)); bias = tin("hl.b", (cout,))
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(wt); conv.bias.copy_(bias)
+    ref = F.conv2d(rnd(x, eng.dtype), rnd(wt, eng.dtype), bias, padding=1)
+    skip, extra = None, {}
+    if pointwise:
+        skip = torch.nn.Conv2d(c2, cout, 1)
+        ws = tin("hl.sw", (cout, c2, 1, 1), scale=1 / math.sqrt(c2)); bs = tin("hl.sb", (cout,)); s_in = tin("hl.s", (m, c2))
+        with torch.no_grad():
+            skip.weight.copy_(ws); skip.bias.copy_(bs)
+        ref = ref + F.conv2d(rnd(s_in, eng.dtype).reshape(bsz, h, wd, c2).permute(0, 3, 1, 2), rnd(ws, eng.dtype), bs)
+        extra = dict(skip=up(eng, s_in))
+    rows = eng.nchw_to_rows(x.to(eng.device), cpad=cin)
+    g = dict(batch=bsz, hin=h, win=wd, hout=h, wout=wd, cin_real=cin, **extra)
+    pw = eng.pack_conv3x3(conv, skip=skip, same_size=True)
+    assert pw.w_halo is not None
+    supported = bool(eng.lib.dm_conv_halo_supported(m, h, wd, cin, rows.stride(0)))
+    assert supported == (m % 128 == 0 and wd <= 32)
+    eng.tile_override = (_lib.TILE_H128x128, sk)
+    try:
+        if not supported:
+            with pytest.raises(RuntimeError):
+                eng.gemm(rows, pw, conv=g)
+            return
+        out = eng.gemm(rows, pw, conv=g)
+        out2 = eng.gemm(rows, pw, conv=g)
+    finally:
+        eng.tile_override = None
+    assert max_rel(eng.rows_to_nchw(out, bsz, cout, h, wd), ref) < tol(eng.dtype)
+    assert torch.equal(out, out2)
+    assert int(eng.ws_sk[:4096].max()) == 0
+
+
 def test_conv3x3_chunk_major_needs_whole_k_tiles(eng):
     """Channel counts that are not whole k-tiles keep the tap-major image whatever the caller promises; the library
     refuses the chunk-major flag for fp32 problems."""

@@ -29,6 +29,39 @@ __device__ int addr_of(int pat, int lane, int j) {
             const int row = (j & 3) * 16 + (lane >> 2);
             return row * 64 + ((lane & 3) << 4);
         }
+        case 6: {  // 80-byte pixel pitch, 16 consecutive pixels per 16 lanes, chunk qp (activation halo image)
+            return ((j & 3) * 16 + c + (j >> 2)) * 80 + (qp << 4);
+        }
+        // 64-byte pixel slots, 16 consecutive slots per 16 lanes starting at slot s0 = pat & 3 (patterns 8 ..): which swizzle
+        // or pitch keeps ds_read_b128 at full rate?
+        case 8: case 9: case 10: case 11: {  // XOR with slot & 3
+            const int slot = (j & 3) * 16 + c + (pat & 3);
+            return slot * 64 + ((qp ^ (slot & 3)) << 4);
+        }
+        case 12: case 13: case 14: case 15: {  // XOR with (slot >> 1) & 3
+            const int slot = (j & 3) * 16 + c + (pat & 3);
+            return slot * 64 + ((qp ^ ((slot >> 1) & 3)) << 4);
+        }
+        case 16: case 17: case 18: case 19: {  // pitch 96
+            const int slot = (j & 3) * 16 + c + (pat & 3);
+            return slot * 96 + (qp << 4);
+        }
+        case 20: case 21: case 22: case 23: {  // pitch 112
+            const int slot = (j & 3) * 16 + c + (pat & 3);
+            return slot * 112 + (qp << 4);
+        }
+        case 24: case 25: case 26: case 27: {  // pitch 144
+            const int slot = (j & 3) * 16 + c + (pat & 3);
+            return slot * 144 + (qp << 4);
+        }
+        case 28: case 29: case 30: case 31: {  // 128-byte rows, ring swizzle, odd starts
+            const int row = (j & 3) * 16 + c + (pat & 3);
+            return row * 128 + (((qp + 4 * (j >> 2)) ^ ((row >> 1) & 7)) << 4);
+        }
+        case 7: {  // 128-byte rows with the GEMM ring's XOR swizzle (reference point)
+            const int row = (j & 3) * 16 + c;
+            return row * 128 + (((qp + 4 * (j >> 2)) ^ ((row >> 1) & 7)) << 4);
+        }
     }
     return 0;
 }
@@ -65,8 +98,8 @@ __global__ void probe(int pat, int iters, long long* out, uint32_t* sink) {
 int main() {
     long long* d; uint32_t* s;
     hipMalloc(&d, 16); hipMalloc(&s, 4 * 1024);
-    for (int waves = 4; waves <= 16; waves *= 4)
-        for (int pat = 0; pat < 6; ++pat) {
+    for (int waves = 16; waves <= 16; waves *= 4)
+        for (int pat = 0; pat < 32; ++pat) {
             hipLaunchKernelGGL(probe, dim3(1), dim3(64 * waves), 16384, 0, pat, 2000, d, s);
             hipDeviceSynchronize();
             long long h[2]; hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
