@@ -378,7 +378,7 @@ def main():
                        "latent": f"{HW}x{HW}", "ddpm_steps": T, "hip_graph": sched.use_hip_graph,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_igemm_kernel + conv3x3_pair_kernel"
-                                                    + (" + conv3x3_chunk_kernel + conv3x3_wide_kernel" if cfg["dtype"] == "bf16"
+                                                    + (" + conv3x3_chunk_kernel + conv3x3_halo_kernel + conv3x3_wide_kernel" if cfg["dtype"] == "bf16"
                                                        else " + conv3x3_gn_kernel" if not split else " (conv3x3_split_kernel)"),
                          "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(tflops / peak, 4), "traffic": pmc_traffic(args.config, B, HW),

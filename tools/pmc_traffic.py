@@ -31,13 +31,13 @@ def klass(name):
     """Kernel class of a dispatch; the conv3x3 kernels (generic ring, 256x256 ping-pong tile, fp32 form that
     normalises its operand) are one class, as are the dense GEMM kernels."""
     m = re.search(r"(conv3x3_igemm_kernel|conv3x3_wide_kernel|conv3x3_gn_kernel|conv3x3_pair_kernel|conv3x3_chunk_kernel|"
-                  r"conv3x3_chunk_pair_kernel|gemm_dma_kernel|"
+                  r"conv3x3_chunk_pair_kernel|conv3x3_halo_kernel|gemm_dma_kernel|"
                   r"gemm_wide_kernel|gemm_gn_kernel|gemm_pair_kernel|gemm_panel_kernel|ffn_geglu_kernel|attn_kernel|"
                   r"gn_stats_kernel|gn_apply_kernel|layernorm_kernel|splitk_reduce_kernel|linear_rows_kernel)", name)
     if not m:
         return None
     return {"conv3x3_igemm_kernel": "conv3x3", "conv3x3_wide_kernel": "conv3x3", "conv3x3_gn_kernel": "conv3x3",
-            "conv3x3_pair_kernel": "conv3x3", "conv3x3_chunk_kernel": "conv3x3", "conv3x3_chunk_pair_kernel": "conv3x3",
+            "conv3x3_pair_kernel": "conv3x3", "conv3x3_chunk_kernel": "conv3x3", "conv3x3_chunk_pair_kernel": "conv3x3", "conv3x3_halo_kernel": "conv3x3",
             "gemm_dma_kernel": "gemm", "gemm_wide_kernel": "gemm", "gemm_gn_kernel": "gemm",
             "gemm_pair_kernel": "gemm", "gemm_panel_kernel": "gemm", "ffn_geglu_kernel": "gemm"}.get(m.group(1), m.group(1))
 
