@@ -536,6 +536,11 @@ class Engine:
         panel = tile.value in _lib.PANEL_TILES  # row-panel form: sk counts column slices, no workspace
         if (ln_in is not None or ln_out) and sk.value > 1 and not panel:
             sk.value = 1  # the separate split-K reduction launch does not carry the LayerNorm epilogue
+        if tile.value == _lib.TILE_H128x128 and self.tile_override is None and (
+                pw.w_halo is None or not self.lib.dm_conv_halo_supported(m, d.hin, d.win, d.cin, d.lda)):
+            # the table keys a convolution by (m, n, k), not by image shape: another geometry with the same key (or weights
+            # packed without the second image) runs on the ring tile of the same size and split
+            tile.value = _lib.TILE_D128x128_S2
         d.tile, d.splitk = tile.value, sk.value
         self._bind_conv_image(d, pw)
         if gn_rec is not None:

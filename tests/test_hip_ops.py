@@ -247,6 +247,37 @@ def test_conv3x3_halo_tile(eng, geom, sk, pointwise):
     assert int(eng.ws_sk[:4096].max()) == 0
 
 
+def test_conv3x3_halo_choice_falls_back(eng):
+    """A table entry that names the halo tile is keyed by (m, n, k), not by image shape: a convolution with the same key on
+    images the tile does not take, or on weights packed without the second image, runs on the ring tile instead."""
+    if eng.dtype != torch.bfloat16:
+        pytest.skip("halo tile: bf16 only")
+    cin, cout = 64, 64
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1)
+    pw = eng.pack_conv3x3(conv, same_size=True)
+    saved = dict(eng.tuned)
+    try:
+        for (bsz, h, wd) in ((1, 2, 128), (1, 16, 16)):  # 128 pixels wide: not taken; 16 x 16: taken
+            m = bsz * h * wd
+            x = torch.randn(bsz, cin, h, wd)
+            rows = eng.nchw_to_rows(x.to(eng.device), cpad=cin)
+            g = dict(batch=bsz, hin=h, win=wd, hout=h, wout=wd, cin_real=cin)
+            key = (m, cout, 9 * cin, 1, 1, 0, _lib.EPI_PLAIN, False, False, False, False, False, 0, "chunk_major")
+            eng.tuned[key] = (_lib.TILE_H128x128, 1)
+            out = eng.gemm(rows, pw, conv=g)
+            ref = F.conv2d(rnd(x, eng.dtype), rnd(conv.weight.detach(), eng.dtype), conv.bias.detach(), padding=1)
+            assert max_rel(eng.rows_to_nchw(out, bsz, cout, h, wd), ref) < tol(eng.dtype)
+            keep, pw.w_halo = pw.w_halo, None
+            try:
+                out = eng.gemm(rows, pw, conv=g)
+            finally:
+                pw.w_halo = keep
+            assert max_rel(eng.rows_to_nchw(out, bsz, cout, h, wd), ref) < tol(eng.dtype)
+    finally:
+        eng.tuned.clear()
+        eng.tuned.update(saved)
+
+
 def test_conv3x3_chunk_major_needs_whole_k_tiles(eng):
     """Channel counts that are not whole k-tiles keep the tap-major image whatever the caller promises; the library
     refuses the chunk-major flag for fp32 problems."""
